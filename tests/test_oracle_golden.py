@@ -1,0 +1,169 @@
+"""Pin the CPU oracle to the reference's own outputs (tests/golden/*.npz, produced
+by tests/golden/make_golden.py from the imported reference).  fp32, tolerance 2e-6
+relative to the tensor's max magnitude (torch CPU fp32 roundoff between two
+orderings of the same arithmetic)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+TOL = 2e-6
+
+
+def _load(golden_dir, name):
+  z = np.load(os.path.join(golden_dir, name))
+  return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _close(a, b, tol=TOL):
+  a, b = a.double(), b.double()
+  scale = max(b.abs().max().item(), 1e-30)
+  err = (a - b).abs().max().item()
+  assert err <= tol * scale, f'max err {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.fixture(scope='module')
+def ops(golden_dir):
+  return _load(golden_dir, 'ops.npz')
+
+
+@pytest.fixture(scope='module')
+def mdl(golden_dir):
+  return _load(golden_dir, 'model.npz')
+
+
+def test_rmsnorm_fwd_bwd(ops):
+  x = ops['rms_x'].clone().requires_grad_(True)
+  w = ops['rms_w'].clone().requires_grad_(True)
+  y = O.rmsnorm(x, w)
+  _close(y.detach(), ops['rms_y'])
+  y.backward(ops['rms_dy'])
+  _close(x.grad, ops['rms_dx'])
+  _close(w.grad, ops['rms_dw'])
+
+
+def test_rope_table_and_apply(ops):
+  cos, sin = O.rope_table(64, 2048)
+  rows = ops['rope_rows'].long()
+  assert torch.equal(cos[rows], ops['rope_cos_rows'])
+  assert torch.equal(sin[rows], ops['rope_sin_rows'])
+  _close(O.rope_apply(ops['rope_q'], cos, sin), ops['rope_qr'])
+  _close(O.rope_apply(ops['rope_k'], cos, sin), ops['rope_kr'])
+
+
+def _docs(ops_or_mdl, key):
+  return [[int(v) for v in row if v > 0] for row in ops_or_mdl[key]]
+
+
+@pytest.mark.parametrize('tag', ['c', 'm'])
+def test_attention_fwd_bwd(ops, tag):
+  q, k, v = (ops[f'att{tag}_{n}'].clone().requires_grad_(True) for n in 'qkv')
+  ds = O.doc_start_from_lengths(_docs(ops, 'attm_docs_lengths'), q.shape[1]) if tag == 'm' else None
+  o = O.attention(q, k, v, ds)
+  _close(o.detach(), ops[f'att{tag}_o'])
+  o.backward(ops[f'att{tag}_do'])
+  for n, t in zip('qkv', (q, k, v)):
+    _close(t.grad, ops[f'att{tag}_d{n}'], 5e-6)
+
+
+def test_doc_mask_matches_reference_mask(ops):
+  ds = O.doc_start_from_lengths(_docs(ops, 'attm_docs_lengths'), 64)
+  assert torch.equal(O.mask_from_doc_start(ds), ops['attm_mask'])
+  # a single document is exactly the causal mask
+  one = O.doc_start_from_lengths([[65]], 64)
+  assert torch.equal(O.mask_from_doc_start(one)[0], torch.ones(64, 64, dtype=torch.bool).tril())
+  with pytest.raises(ValueError):
+    O.doc_start_from_lengths([[10, 10]], 64)
+
+
+def test_glu_hidden_dim_and_fwd_bwd(ops):
+  for d, ex, h in zip(ops['hid_dim'], ops['hid_expand'], ops['hid_out']):
+    assert O.glu_hidden_dim(int(d), float(ex)) == int(h)
+  assert O.parse_expand('8/3') == 8 / 3
+  x = ops['glu_x'].clone().requires_grad_(True)
+  w1 = ops['glu_w1'].clone().requires_grad_(True)
+  w2 = ops['glu_w2'].clone().requires_grad_(True)
+  y = O.swiglu(x @ w1.t(), w2.shape[1]) @ w2.t()
+  _close(y.detach(), ops['glu_y'])
+  y.backward(ops['glu_dy'])
+  _close(x.grad, ops['glu_dx'])
+  _close(w1.grad, ops['glu_dw1'])
+  _close(w2.grad, ops['glu_dw2'])
+
+
+def test_cross_entropy(ops):
+  lg = ops['ce_logits'].clone().requires_grad_(True)
+  loss = O.cross_entropy(lg, ops['ce_targets'])
+  _close(loss.detach(), ops['ce_loss'])
+  loss.backward()
+  _close(lg.grad, ops['ce_dlogits'])
+
+
+def test_embedding_repeated_ids(ops):
+  w = ops['emb_w'].clone().requires_grad_(True)
+  out = w[ops['emb_ids']]
+  assert torch.equal(out.detach(), ops['emb_out'])
+  out.backward(ops['emb_dout'])
+  _close(w.grad, ops['emb_dw'])
+
+
+def _model_cfg():
+  return O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2)
+
+
+def _weights(mdl):
+  return {k[2:]: v for k, v in mdl.items() if k.startswith('w:')}
+
+
+def test_param_names_shapes_init(mdl):
+  cfg = _model_cfg()
+  w = _weights(mdl)
+  assert list(w) == O.param_names(cfg)
+  assert {n: tuple(t.shape) for n, t in w.items()} == O.param_shapes(cfg)
+  # init distribution statistics of the reference (transformer.py:116-129)
+  mine = O.init_params(cfg, seed=3)
+  for i, n in enumerate(O.param_names(cfg)):
+    ref_std = float(mdl['init_std'][i])
+    if 'norm' in n:
+      assert torch.equal(mine[n], torch.ones_like(mine[n])) and ref_std == 0.0
+    else:
+      assert abs(mine[n].std().item() - ref_std) < 0.06 * ref_std, n
+      assert abs(mine[n].mean().item()) < 4 * ref_std / np.sqrt(mine[n].numel()) + 1e-4
+
+
+def test_model_forward_backward(mdl):
+  cfg = _model_cfg()
+  w = _weights(mdl)
+  tok = mdl['tokens']
+  ids, tgt = tok[:, :64], tok[:, 1:65]
+  _close(O.forward(w, cfg, ids), mdl['logits'])
+  ds = O.doc_start_from_lengths(_docs(mdl, 'docs_lengths'), 64)
+  _close(O.forward(w, cfg, ids, ds), mdl['logits_docmask'])
+  loss, grads = O.loss_and_grads(w, cfg, ids, tgt)
+  _close(loss, mdl['loss'])
+  for n in O.param_names(cfg):
+    _close(grads[n], mdl['g:' + n], 5e-6)
+
+
+def test_engine_loss_sequence(mdl, golden_dir):
+  """engine/engine.py:93-141 over 4 optimizer steps (accum 4, clip 1.0, AdamW, warmup-cosine)."""
+  en = _load(golden_dir, 'engine.npz')
+  cfg = _model_cfg()
+  eng = O.OracleEngine(_weights(mdl), cfg, lr=3e-3, weight_decay=0.1, beta1=0.9, beta2=0.95, grad_clip=1.0,
+                       accum=4, steps_budget=8, warmup_steps=2)
+  losses, lrs, norms = [], [], []
+  for i in range(en['tokens'].shape[0]):
+    losses.append(eng.step({'input_ids': en['tokens'][i]}).item())
+    if (i + 1) % 4 == 0:
+      lrs.append(eng.lr)
+      norms.append([eng.params[n].norm().item() for n in O.param_names(cfg)])
+  np.testing.assert_allclose(losses, en['losses'].numpy(), rtol=2e-6)
+  np.testing.assert_allclose(lrs, en['lrs'].numpy(), rtol=1e-12)
+  np.testing.assert_allclose(norms, en['param_norms'].numpy(), rtol=5e-6)
+  _close(eng.params['layers.1.mlp.fc2.weight'], en['final:layers.1.mlp.fc2.weight'], 5e-5)
+  _close(eng.params['out_norm.weight'], en['final:out_norm.weight'], 5e-6)
+  _close(eng.params['embed_tokens.weight'][:16], en['final:embed_rows'], 5e-5)
