@@ -1,0 +1,139 @@
+/* plainlm_hip.h — C ABI of libplainlm_hip.so (MI355X / gfx950 only).
+ *
+ * plainLM has no FFI of its own: its hot path is Python calling torch ops
+ * (SURVEY.md §8b).  Each entry point below therefore cites the torch call site
+ * in the reference that it replaces (paths relative to the reference root).
+ *
+ * Conventions (identical for every function):
+ *   - all pointers are DEVICE pointers owned by the caller (workspaces too);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on
+ *     that stream, never synchronises, never allocates;
+ *   - bf16 tensors are passed as uint16_t* (raw bfloat16 bits), row-major;
+ *   - return value: 0 = ok, <0 = error (PLM_E_*); plm_last_error_string()
+ *     returns a thread-local description of the last failure on this thread;
+ *   - re-entrant and thread-safe per stream (autograd's backward thread differs
+ *     from the forward thread).
+ */
+#ifndef PLAINLM_HIP_H
+#define PLAINLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLM_OK 0
+#define PLM_E_INVALID (-1)     /* bad argument / unsupported shape */
+#define PLM_E_HIP (-2)         /* a HIP runtime call or launch failed */
+#define PLM_E_COMM (-3)        /* RCCL failure */
+#define PLM_E_WORKSPACE (-4)   /* caller-provided workspace too small */
+
+int plm_version(void);
+const char* plm_last_error_string(void);
+
+/* ---- parameter casts --------------------------------------------------
+ * Replaces autocast's per-forward fp32->bf16 weight casts
+ * (engine/engine.py:75,108-109).  The `_t` form also writes the transposed
+ * copy dst_t[cols, rows] used by the dX GEMMs. */
+int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols, void* stream);
+
+/* ---- embedding (models/transformer.py:94,110) --------------------------
+ * fwd: out[m,:] = W[ids[m],:]           ids int64[M], W fp32[V,d], out fp32[M,d]
+ * bwd: dW[ids[m],:] += dout[m,:]        (atomic fp32 adds; dW must be initialised) */
+int plm_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t M, int64_t d, int64_t V, void* stream);
+int plm_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t M, int64_t d, int64_t V, void* stream);
+
+/* ---- RMSNorm (+ residual add) (models/components.py:16-28, transformer.py:81-82)
+ * fwd:  r = x (+ branch if branch != NULL)          x fp32[M,d], branch bf16[M,d]
+ *       if xout != NULL: xout = r                    fp32[M,d]  (may alias x)
+ *       rstd[m] = rsqrt(mean(r^2) + eps)             fp32[M]
+ *       y = bf16((r * rstd) * w)                     bf16[M,d]
+ * bwd:  a = dy * w ; dxn = rstd*a - x*rstd^3*mean(a*x)
+ *       dx = (gin ? gin : 0) + dxn                   fp32[M,d]  (may alias gin)
+ *       if dx_bf16 != NULL: dx_bf16 = bf16(dx)
+ *       dw_partial[blk,:] = sum over the block's rows of dy*x*rstd   fp32[nblk,d]
+ *       nblk = plm_rmsnorm_bwd_blocks(M); reduce with plm_colsum_f32. */
+int plm_rmsnorm_fwd(const float* x, const uint16_t* branch, float* xout, const float* w, uint16_t* y, float* rstd,
+                    int64_t M, int64_t d, float eps, void* stream);
+int64_t plm_rmsnorm_bwd_blocks(int64_t M);
+int plm_rmsnorm_bwd(const uint16_t* dy, const float* x, const float* w, const float* rstd, const float* gin,
+                    float* dx, uint16_t* dx_bf16, float* dw_partial, int64_t M, int64_t d, void* stream);
+/* out[j] (+)= sum_r part[r, j]; accumulate != 0 adds into out. */
+int plm_colsum_f32(const float* part, float* out, int64_t rows, int64_t cols, int accumulate, void* stream);
+
+/* ---- SwiGLU gate (models/components.py:55-56) ---------------------------
+ * u bf16[M,2h] = fc1 output, x = u[:, :h], z = u[:, h:]
+ * fwd: out = bf16(bf16(silu(x)) * z)                          bf16[M,h]
+ * bwd: du[:, :h] = d/dx, du[:, h:] = d/dz (bf16 autograd chain of the reference) */
+int plm_swiglu_fwd(const uint16_t* u, uint16_t* out, int64_t M, int64_t h, void* stream);
+int plm_swiglu_bwd(const uint16_t* dout, const uint16_t* u, uint16_t* du, int64_t M, int64_t h, void* stream);
+
+/* ---- bf16 MFMA GEMMs (nn.Linear: transformer.py:36-37,42,67,97,114; components.py:50-51)
+ * nt: C[M,N] = alpha * A[M,K] · B[N,K]^T        A,B bf16 K-contiguous (y = x W^T, and dX = dY (W^T)^T)
+ * tn: C[M,N] (+)= alpha * A[K,M]^T · B[K,N]     A,B bf16, contraction over rows (dW = dY^T X), C fp32
+ * c_dtype: 0 = bf16, 1 = fp32.  accumulate (fp32 C only): C += result.
+ * alpha_dev: optional device pointer to one fp32 scale (NULL = 1).
+ * Requirements: K % 8 == 0 (nt) ; M % 8 == 0 and N % 8 == 0 (tn); ld* % 8 == 0; 16-byte aligned bases.
+ * tn splits the contraction over `splits` slabs when M*N is too small to fill the chip; it needs a
+ * fp32 workspace of plm_gemm_tn_workspace_bytes(M,N,K) bytes (0 when no split is used). */
+int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream);
+size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int accumulate, const float* alpha_dev,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- causal / document-masked attention with in-kernel RoPE
+ * (models/transformer.py:43-65, models/embeddings.py:15-30, data/datasets/data_prep_utils.py:7-23)
+ * qkv bf16[B*T, 3*nh*hd] straight from w_qkv (q | k | v column blocks, head h = cols h*hd..), hd == 64.
+ * rope_cos/sin fp32[T, hd/2] (interleaved-pair convention).  doc_start int32[B,T] or NULL (pure causal):
+ * query i attends key j iff doc_start[i] <= j <= i.
+ * fwd: out bf16[B*T, nh*hd], lse fp32[B, nh, T] (natural-log LSE of the scaled scores)
+ * bwd: dqkv bf16[B*T, 3*nh*hd] (gradient w.r.t. the PRE-rotation q,k and v); delta fp32[B,nh,T] scratch. */
+int plm_attn_fwd(const uint16_t* qkv, const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
+                 uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream);
+int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
+                 const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
+                 uint16_t* dqkv, float* delta, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream);
+
+/* ---- fused cross-entropy forward+backward (engine/engine.py:81,111) -----
+ * logits bf16[M,V] are OVERWRITTEN with dlogits = (softmax - onehot) * grad_scale  (grad_scale = g/M).
+ * loss_rows fp32[M] = logsumexp(l) - l[target].  Then plm_mean_f32 reduces to the scalar mean. */
+int plm_ce_fwd_bwd(uint16_t* logits, const int64_t* targets, float* loss_rows, int64_t M, int64_t V,
+                   float grad_scale, void* stream);
+int plm_mean_f32(const float* x, float* out, int64_t n, void* stream);
+
+/* ---- optimizer tail (engine/engine.py:126-135, optim/init_optim.py:14-21)
+ * sumsq: out[0] = sum(x^2) (single-launch deterministic two-stage reduce; scratch >= 4096 floats)
+ * adamw: decoupled-weight-decay Adam on a flat fp32 span, matching torch.optim.AdamW:
+ *   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps), with g pre-multiplied by *clip_coef_dev (NULL = 1). */
+int plm_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, void* stream);
+int plm_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float bc1, float bc2, const float* clip_coef_dev, void* stream);
+
+/* ---- RCCL data-parallel gradient exchange (replaces DDP: engine/engine.py:64-65,104-105)
+ * One communicator per process (one process per GPU).  uid is the 128-byte ncclUniqueId
+ * produced by plm_comm_unique_id on rank 0 and shipped to the other ranks by the host. */
+typedef struct plm_comm plm_comm_t;
+int plm_comm_unique_id(uint8_t uid[128]);
+int plm_comm_init(plm_comm_t** comm, const uint8_t uid[128], int rank, int world_size, int device);
+int plm_comm_destroy(plm_comm_t* comm);
+/* in-place all-reduce-mean of a fp32 span on `stream` (the side stream owned by the caller) */
+int plm_comm_allreduce_avg_f32(plm_comm_t* comm, float* buf, int64_t count, void* stream);
+int plm_comm_broadcast_f32(plm_comm_t* comm, float* buf, int64_t count, int root, void* stream);
+
+/* ---- hardware probes used by the GPU tests (semantics of gfx950 instructions the kernels rely on)
+ * out int32[64*4]: element [lane*4+j] = value lane received in slot j from ds_read_b64_tr_b16 when
+ * lane l supplied address base + 8*l bytes and LDS held the uint16 sequence 0,1,2,... */
+int plm_probe_ds_read_tr16(int32_t* out, void* stream);
+/* out fp32[32*32] = A·B for A[32,16], B[16,32] given as fp32 row-major (rounded to bf16), one wave */
+int plm_probe_mfma32(const float* A, const float* B, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLAINLM_HIP_H */

@@ -1,0 +1,582 @@
+// Flash-style causal / document-masked attention for gfx950 with RoPE applied in-kernel.
+// Replaces models/transformer.py:43-65 (split, RoPE, transposes, SDPA, transpose back) and
+// models/embeddings.py:15-30; the mask of data/datasets/data_prep_utils.py:7-23 is expressed as
+// doc_start[B,T] (query i sees key j iff doc_start[i] <= j <= i; doc_start is non-decreasing in i).
+//
+// q, k, v are read strided straight out of the w_qkv output [B*T, 3*nh*64]; no transposed copies.
+// All matrix products are v_mfma_f32_32x32x16_bf16.  Scores are computed TRANSPOSED
+// (S^T[kv][q] = K·Q^T) so a lane owns one query column: row max / row sum are in-lane plus one
+// cross-half shuffle, and the probabilities are already in the B-operand layout of the following
+// P·V product (no LDS round trip for P).  The V / K / Q / dO operands whose contraction index is the
+// token row are fetched with ds_read_b64_tr_b16 (hardware transpose) from the same LDS image that
+// serves the ds_read_b128 operands.
+//
+// LDS image of a [R rows][64 d] bf16 tile ("swizzled sub-tiles"):
+//   byte(row, d) = (d>>4)*(R*32+128) + row*32 + ((((d>>3)&1) ^ ((row>>3)&1))<<4) + (d&7)*2
+// 16-column sub-tiles make a transpose-read block (4 rows x 32 B) contiguous; the 128-byte pad puts the
+// two sub-tiles touched by one 32-lane half on different bank halves; the (row>>3)&1 swizzle of the
+// 16-byte halves makes ds_read_b128 across rows r and r+8 conflict-free.
+#include "plm_device.h"
+
+#define HD 64
+#define LOG2E 1.4426950408889634f
+
+template <int R>
+__device__ __forceinline__ int tile_off(int row, int d) {
+  return (d >> 4) * (R * 32 + 128) + row * 32 + ((((d >> 3) & 1) ^ ((row >> 3) & 1)) << 4) + (d & 7) * 2;
+}
+
+// interleaved-pair rotation of 8 consecutive head dims (4 pairs); sgn = +1 forward, -1 inverse (gradient)
+__device__ __forceinline__ bf16x8_t rope8(bf16x8_t v, f32x4_t c, f32x4_t s, float sgn) {
+  bf16x8_t o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = bf2f(v[2 * p]), b = bf2f(v[2 * p + 1]);
+    const float sn = s[p] * sgn;
+    o[2 * p] = f2bf(a * c[p] - b * sn);
+    o[2 * p + 1] = f2bf(b * c[p] + a * sn);
+  }
+  return o;
+}
+
+// staging map of a [64 rows][64 d] tile over 256 threads, 2 chunks (16 B) each: an 8-lane store group
+// covers 2 rows x 4 chunks (2 sub-tiles) = 8 distinct 16-byte slots mod 256 (conflict-free ds_write_b128)
+__device__ __forceinline__ void stage_map(int idx, int& row, int& chunk) {
+  const int u = idx & 7, rest = idx >> 3;
+  chunk = (rest & 1) * 4 + (u & 3);
+  row = ((rest >> 1) << 1) | (u >> 2);
+}
+
+// A-operand fragment (rows i = tile rows, k = head dims ks*16 + hi*8 ..) by ds_read_b128
+template <int R>
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row, int ks, int hi) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + tile_off<R>(row, ks * 16 + hi * 8));
+}
+// A-operand fragment (rows i = head dims db*32 + (lane&31), k = tile rows) by two transpose reads.
+// k-slot e of lane-half hi maps to tile row  rbase + (e&3) + 8*(e>>2)  — the row order in which a lane
+// holds the matching B operand after a transposed-score MFMA (see mfma32_row()).
+template <int R>
+__device__ __forceinline__ bf16x8_t frag_cols(const char* tile, int db, int rbase, int lane) {
+  const int ib = (lane >> 4) & 1, t16 = lane & 15;
+  const int row = rbase + (t16 >> 2);
+  const int sub = db * 2 + ib;
+  const int half = (t16 & 3) >> 1;
+  const char* p0 = tile + sub * (R * 32 + 128) + row * 32 + ((half ^ ((row >> 3) & 1)) << 4) + (t16 & 1) * 8;
+  const int row1 = row + 8;
+  const char* p1 = tile + sub * (R * 32 + 128) + row1 * 32 + ((half ^ ((row1 >> 3) & 1)) << 4) + (t16 & 1) * 8;
+  return join_tr(lds_read_tr16(p0), lds_read_tr16(p1));
+}
+
+__device__ __forceinline__ void zero16(f32x16_t& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <bool HAS_DOC>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
+                                                       const float* __restrict__ rsin, const int32_t* __restrict__ doc_start,
+                                                       uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
+  constexpr int KT = 64;  // kv rows per tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (KT * 32 + 128)];
+  char* sK = smem;
+  char* sV = smem + 4 * (KT * 32 + 128);
+
+  const int nqt = gridDim.x;
+  const int qt = nqt - 1 - blockIdx.x;  // heaviest (latest) query tiles first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int q0 = qt * 128;
+  const int qw0 = q0 + wave * 32;
+  const int qrow = qw0 + l31;
+  const bool qvalid = qrow < T;
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const float scale = 0.125f;  // 1/sqrt(64)
+  const float c2 = scale * LOG2E;
+
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = ks * 16 + hi * 8;
+    qf[ks] = zero_bf16x8();
+    if (qvalid) {
+      const bf16x8_t raw = ld_bf16x8(base + (int64_t)qrow * ld + d0);
+      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + qrow * 32 + d0 / 2);
+      const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + qrow * 32 + d0 / 2);
+      qf[ks] = rope8(raw, cs, sn, 1.f);
+    }
+  }
+  int dsq = 0;
+  if (HAS_DOC && qvalid) dsq = doc_start[(int64_t)b * T + qrow];
+
+  f32x16_t o[2];
+  zero16(o[0]);
+  zero16(o[1]);
+  float m = -INFINITY, lsum = 0.f;
+
+  const int kv_hi = min(T, q0 + 128);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  int jt_lo = 0;
+  if (HAS_DOC) jt_lo = doc_start[(int64_t)b * T + q0] / KT;
+
+  // staging registers (next tile in flight during compute)
+  int srow[2], schunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
+  bf16x8_t rk[2], rv[2];
+  f32x4_t rc[2], rs[2];
+  auto g_load = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kv = kv0 + srow[i];
+      rk[i] = zero_bf16x8();
+      rv[i] = zero_bf16x8();
+      rc[i] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+      rs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (kv < T) {
+        const uint16_t* p = base + (int64_t)kv * ld + schunk[i] * 8;
+        rk[i] = ld_bf16x8(p + dm);
+        rv[i] = ld_bf16x8(p + 2 * dm);
+        rc[i] = *reinterpret_cast<const f32x4_t*>(rcos + kv * 32 + schunk[i] * 4);
+        rs[i] = *reinterpret_cast<const f32x4_t*>(rsin + kv * 32 + schunk[i] * 4);
+      }
+    }
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = tile_off<KT>(srow[i], schunk[i] * 8);
+      *reinterpret_cast<bf16x8_t*>(sK + off) = rope8(rk[i], rc[i], rs[i], 1.f);
+      *reinterpret_cast<bf16x8_t*>(sV + off) = rv[i];
+    }
+  };
+
+  if (jt_lo < jt_hi) {
+    g_load(jt_lo * KT);
+    s_store();
+  }
+  __syncthreads();
+  for (int jt = jt_lo; jt < jt_hi; ++jt) {
+    const int kv0 = jt * KT;
+    if (jt + 1 < jt_hi) g_load((jt + 1) * KT);
+    const bool wave_active = kv0 <= qw0 + 31;  // tile not entirely above this wave's diagonal
+    if (wave_active) {
+      f32x16_t s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        zero16(s[kb]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s[kb]);
+      }
+      const bool need_mask = HAS_DOC || (kv0 + KT - 1 > qw0);
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (need_mask) {
+            const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+            const bool ok = (kvg <= qrow) && (!HAS_DOC || kvg >= dsq);
+            if (!ok) s[kb][r] = -INFINITY;
+          }
+          tmax = fmaxf(tmax, s[kb][r]);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f((m - m_safe) * c2);
+      const float mc = m_safe * c2;
+      float psum = 0.f;
+      bf16x8_t pf[4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = exp2f(s[kb][r] * c2 - mc);
+          psum += p;
+          pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
+        }
+      }
+      lsum = lsum * alpha + psum;
+      m = m_new;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          const int rbase = (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi;
+          o[db] = mfma32(frag_cols<KT>(sV, db, rbase, lane), pf[sp], o[db]);
+        }
+      }
+    }
+    __syncthreads();
+    if (jt + 1 < jt_hi) {
+      s_store();
+      __syncthreads();
+    }
+  }
+
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (qvalid) {
+    const float inv = 1.f / ltot;
+    uint16_t* op = out + ((int64_t)b * T + qrow) * dm + h * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[db][4 * g + e] * inv);
+        st_bf16x4(op + db * 32 + 8 * g + 4 * hi, v);
+      }
+    }
+    if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = m * scale + logf(ltot);
+  }
+}
+
+// =============================================================================================
+// backward pre-pass: delta[b,h,q] = sum_d dO * O
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t BT, int T, int nh) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BT) return;
+  const int dm = nh * HD;
+  const int64_t b = row / T;
+  const int q = (int)(row - b * T);
+  for (int c = lane; c < dm / 8; c += 64) {
+    const bf16x8_t a = ld_bf16x8(out + row * dm + c * 8);
+    const bf16x8_t g = ld_bf16x8(dout + row * dm + c * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(g[e]);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if ((lane & 7) == 0) delta[(b * nh + (c >> 3)) * T + q] = s;
+  }
+}
+
+// =============================================================================================
+// backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows)
+// =============================================================================================
+template <bool HAS_DOC>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                            const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv,
+                                                            int T, int nh) {
+  constexpr int QT = 64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (QT * 32 + 128) + 3 * QT * 4];
+  char* sQ = smem;
+  char* sDO = smem + 4 * (QT * 32 + 128);
+  float* sL = reinterpret_cast<float*>(smem + 2 * 4 * (QT * 32 + 128));
+  float* sD = sL + QT;
+  int* sDS = reinterpret_cast<int*>(sD + QT);
+
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int kv0 = kt * 128;
+  const int kvrow = kv0 + wave * 32 + l31;
+  const bool kvalid = kvrow < T;
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
+  const float* lrow = lse + ((int64_t)b * nh + h) * T;
+  const float* drow = delta + ((int64_t)b * nh + h) * T;
+  const float scale = 0.125f, c2 = scale * LOG2E;
+
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = ks * 16 + hi * 8;
+    kf[ks] = zero_bf16x8();
+    vf[ks] = zero_bf16x8();
+    if (kvalid) {
+      const uint16_t* p = base + (int64_t)kvrow * ld + d0;
+      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + kvrow * 32 + d0 / 2);
+      const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + kvrow * 32 + d0 / 2);
+      kf[ks] = rope8(ld_bf16x8(p + dm), cs, sn, 1.f);
+      vf[ks] = ld_bf16x8(p + 2 * dm);
+    }
+  }
+  f32x16_t dk[2], dv[2];
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+
+  int srow[2], schunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
+
+  const int nqt = (T + QT - 1) / QT;
+  for (int jq = kv0 / QT; jq < nqt; ++jq) {
+    const int qt0 = jq * QT;
+    if (HAS_DOC) {
+      // doc_start is non-decreasing: once the first row of a query tile starts after this key block,
+      // no later query can see these keys
+      if (doc_start[(int64_t)b * T + qt0] > kv0 + 127) break;
+    }
+    // ---- stage Q (rotated) and dO, plus per-row lse / delta / doc_start
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = qt0 + srow[i];
+      bf16x8_t rq = zero_bf16x8(), rdo = zero_bf16x8();
+      if (q < T) {
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + q * 32 + schunk[i] * 4);
+        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + q * 32 + schunk[i] * 4);
+        rq = rope8(ld_bf16x8(base + (int64_t)q * ld + schunk[i] * 8), cs, sn, 1.f);
+        rdo = ld_bf16x8(dobase + (int64_t)q * dm + schunk[i] * 8);
+      }
+      const int off = tile_off<QT>(srow[i], schunk[i] * 8);
+      *reinterpret_cast<bf16x8_t*>(sQ + off) = rq;
+      *reinterpret_cast<bf16x8_t*>(sDO + off) = rdo;
+    }
+    if (t < QT) {
+      const int q = qt0 + t;
+      sL[t] = (q < T) ? lrow[q] : 0.f;
+      sD[t] = (q < T) ? drow[q] : 0.f;
+      sDS[t] = (HAS_DOC && q < T) ? doc_start[(int64_t)b * T + q] : 0;
+    }
+    __syncthreads();
+
+    const bool wave_active = qt0 + QT - 1 >= kv0 + wave * 32;  // some query at or below this wave's first key
+    if (wave_active) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16_t s, dp;
+        zero16(s);
+        zero16(dp);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma32(frag_rows<QT>(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
+          dp = mfma32(frag_rows<QT>(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
+        }
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = qb * 32 + mfma32_row(r, hi);
+          const int qg = qt0 + ql;
+          bool ok = (kvrow <= qg) && (qg < T);
+          if (HAS_DOC) ok = ok && (kvrow >= sDS[ql]);
+          const float p = ok ? exp2f(s[r] * c2 - sL[ql] * LOG2E) : 0.f;
+          const float dsv = p * (dp[r] - sD[ql]) * scale;
+          pf[r >> 3][r & 7] = f2bf(p);
+          dsf[r >> 3][r & 7] = f2bf(dsv);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int rbase = qb * 32 + s2 * 16 + 4 * hi;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = mfma32(frag_cols<QT>(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
+            dk[db] = mfma32(frag_cols<QT>(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (kvalid) {
+    uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
+    uint16_t* dvp = dkp + dm;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        bf16x4_t ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
+        st_bf16x4(dvp + d0, ov);
+        // inverse rotation of the two (even, odd) pairs of dK
+        const float c0 = rcos[kvrow * 32 + d0 / 2], c1 = rcos[kvrow * 32 + d0 / 2 + 1];
+        const float s0 = rsin[kvrow * 32 + d0 / 2], s1 = rsin[kvrow * 32 + d0 / 2 + 1];
+        const float a0 = dk[db][4 * g + 0], b0 = dk[db][4 * g + 1], a1 = dk[db][4 * g + 2], b1 = dk[db][4 * g + 3];
+        bf16x4_t ok;
+        ok[0] = f2bf(a0 * c0 + b0 * s0);
+        ok[1] = f2bf(b0 * c0 - a0 * s0);
+        ok[2] = f2bf(a1 * c1 + b1 * s1);
+        ok[3] = f2bf(b1 * c1 - a1 * s1);
+        st_bf16x4(dkp + d0, ok);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows)
+// =============================================================================================
+template <bool HAS_DOC>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                          const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv, int T,
+                                                          int nh) {
+  constexpr int KT = 64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (KT * 32 + 128)];
+  char* sK = smem;
+  char* sV = smem + 4 * (KT * 32 + 128);
+
+  const int nqt = gridDim.x;
+  const int qt = nqt - 1 - blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int q0 = qt * 128, qw0 = q0 + wave * 32, qrow = qw0 + l31;
+  const bool qvalid = qrow < T;
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const float scale = 0.125f, c2 = scale * LOG2E;
+
+  bf16x8_t qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = ks * 16 + hi * 8;
+    qf[ks] = zero_bf16x8();
+    dof[ks] = zero_bf16x8();
+    if (qvalid) {
+      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + qrow * 32 + d0 / 2);
+      const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + qrow * 32 + d0 / 2);
+      qf[ks] = rope8(ld_bf16x8(base + (int64_t)qrow * ld + d0), cs, sn, 1.f);
+      dof[ks] = ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + d0);
+    }
+  }
+  float Lq = 0.f, Dq = 0.f;
+  int dsq = 0;
+  if (qvalid) {
+    Lq = lse[((int64_t)b * nh + h) * T + qrow] * LOG2E;
+    Dq = delta[((int64_t)b * nh + h) * T + qrow];
+    if (HAS_DOC) dsq = doc_start[(int64_t)b * T + qrow];
+  }
+  f32x16_t dq[2];
+  zero16(dq[0]);
+  zero16(dq[1]);
+
+  int srow[2], schunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
+
+  const int kv_hi = min(T, q0 + 128);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  int jt_lo = 0;
+  if (HAS_DOC) jt_lo = doc_start[(int64_t)b * T + q0] / KT;
+
+  for (int jt = jt_lo; jt < jt_hi; ++jt) {
+    const int kv0 = jt * KT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kv = kv0 + srow[i];
+      bf16x8_t rk = zero_bf16x8(), rv = zero_bf16x8();
+      if (kv < T) {
+        const uint16_t* p = base + (int64_t)kv * ld + schunk[i] * 8;
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + kv * 32 + schunk[i] * 4);
+        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + kv * 32 + schunk[i] * 4);
+        rk = rope8(ld_bf16x8(p + dm), cs, sn, 1.f);
+        rv = ld_bf16x8(p + 2 * dm);
+      }
+      const int off = tile_off<KT>(srow[i], schunk[i] * 8);
+      *reinterpret_cast<bf16x8_t*>(sK + off) = rk;
+      *reinterpret_cast<bf16x8_t*>(sV + off) = rv;
+    }
+    __syncthreads();
+    const bool wave_active = kv0 <= qw0 + 31;
+    if (wave_active) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16_t s, dp;
+        zero16(s);
+        zero16(dp);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
+          dp = mfma32(frag_rows<KT>(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
+        }
+        bf16x8_t dsf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+          bool ok = (kvg <= qrow);
+          if (HAS_DOC) ok = ok && (kvg >= dsq);
+          const float p = ok ? exp2f(s[r] * c2 - Lq) : 0.f;
+          dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq) * scale);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int rbase = kb * 32 + s2 * 16 + 4 * hi;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols<KT>(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (qvalid) {
+    uint16_t* dqp = dqkv + ((int64_t)b * T + qrow) * ld + h * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        const float c0 = rcos[qrow * 32 + d0 / 2], c1 = rcos[qrow * 32 + d0 / 2 + 1];
+        const float s0 = rsin[qrow * 32 + d0 / 2], s1 = rsin[qrow * 32 + d0 / 2 + 1];
+        const float a0 = dq[db][4 * g + 0], b0 = dq[db][4 * g + 1], a1 = dq[db][4 * g + 2], b1 = dq[db][4 * g + 3];
+        bf16x4_t ov;
+        ov[0] = f2bf(a0 * c0 + b0 * s0);
+        ov[1] = f2bf(b0 * c0 - a0 * s0);
+        ov[2] = f2bf(a1 * c1 + b1 * s1);
+        ov[3] = f2bf(b1 * c1 - a1 * s1);
+        st_bf16x4(dqp + d0, ov);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, int64_t hd) {
+  PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
+  PLM_REQUIRE(B > 0 && T > 0 && nh > 0 && B < 65536 && nh < 65536 && T < (1 << 24), "%s: bad shape B=%ld T=%ld nh=%ld", name, (long)B,
+              (long)T, (long)nh);
+  return PLM_OK;
+}
+
+extern "C" int plm_attn_fwd(const uint16_t* qkv, const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
+                            uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream) {
+  PLM_REQUIRE(qkv && rope_cos && rope_sin && out && lse, "plm_attn_fwd: null pointer");
+  if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
+  const dim3 grid((unsigned)plm_cdiv(T, 128), (unsigned)nh, (unsigned)B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (doc_start)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, qkv, rope_cos, rope_sin, doc_start, out, lse, (int)T, (int)nh);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, qkv, rope_cos, rope_sin, doc_start, out, lse, (int)T, (int)nh);
+  PLM_CHECK_LAUNCH("plm_attn_fwd");
+  return PLM_OK;
+}
+
+extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, const float* rope_cos,
+                            const float* rope_sin, const int32_t* doc_start, uint16_t* dqkv, float* delta, int64_t B, int64_t T,
+                            int64_t nh, int64_t hd, void* stream) {
+  PLM_REQUIRE(qkv && out && dout && lse && rope_cos && rope_sin && dqkv && delta, "plm_attn_bwd: null pointer");
+  if (int rc = check_attn_shape("plm_attn_bwd", B, T, nh, hd)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 block(256);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)plm_cdiv(B * T, 4)), block, 0, s, out, dout, delta, B * T, (int)T, (int)nh);
+  const dim3 gkv((unsigned)plm_cdiv(T, 128), (unsigned)nh, (unsigned)B);
+  if (doc_start) {
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+  }
+  PLM_CHECK_LAUNCH("plm_attn_bwd");
+  return PLM_OK;
+}

@@ -1,0 +1,475 @@
+// HBM-bound kernels of the plainLM hot path for gfx950: parameter casts, embedding,
+// RMSNorm (+residual), SwiGLU gate, small reductions and the AdamW tail.
+// One wave (64 lanes) owns one row wherever a row reduction is needed; every global
+// access is 8 or 16 bytes per lane and coalesced along the row.
+#include "plm_device.h"
+
+// ===========================================================================
+// fp32 -> bf16 casts   (autocast weight casts, engine/engine.py:75)
+// ===========================================================================
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                            int64_t n) {
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + i * 8);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + i * 8 + 4);
+    bf16x8_t o;
+    o[0] = f2bf(a[0]); o[1] = f2bf(a[1]); o[2] = f2bf(a[2]); o[3] = f2bf(a[3]);
+    o[4] = f2bf(b[0]); o[5] = f2bf(b[1]); o[6] = f2bf(b[2]); o[7] = f2bf(b[3]);
+    st_bf16x8(dst + i * 8, o);
+  }
+  // tail (n not a multiple of 8)
+  const int64_t tail0 = nvec << 3;
+  const int64_t t = tail0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) reinterpret_cast<bf16_t*>(dst)[t] = f2bf(src[t]);
+}
+
+// 64x64 tile: write dst (same layout) and dst_t (transposed) from one read of src.
+__global__ __launch_bounds__(256) void cast_f32_bf16_t_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                              uint16_t* __restrict__ dst_t, int64_t rows, int64_t cols) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];  // [col][row], 144-byte rows (16B aligned)
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+    const int64_t gr = r0 + r, gc = c0 + c;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (gr < rows && gc < cols) v = *reinterpret_cast<const f32x4_t*>(src + gr * cols + gc);
+    bf16x4_t o;
+    o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+    if (gr < rows && gc < cols) st_bf16x4(dst + gr * cols + gc, o);
+    tile[c + 0][r] = o[0]; tile[c + 1][r] = o[1]; tile[c + 2][r] = o[2]; tile[c + 3][r] = o[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (t >> 3) + 32 * i, rch = (t & 7) * 8;
+    const int64_t gc = c0 + c, gr = r0 + rch;
+    if (gc < cols && gr < rows) {
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&tile[c][rch]);
+      st_bf16x8(dst_t + gc * rows + gr, v);
+    }
+  }
+}
+
+extern "C" int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+  PLM_REQUIRE(src && dst && n >= 0, "plm_cast_f32_bf16: null pointer or negative n");
+  if (n == 0) return PLM_OK;
+  const int64_t work = plm_cdiv(plm_cdiv(n, 8), 256);
+  const int grid = (int)(work < 4096 ? (work < 1 ? 1 : work) : 4096);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  PLM_CHECK_LAUNCH("plm_cast_f32_bf16");
+  return PLM_OK;
+}
+
+extern "C" int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols,
+                                   void* stream) {
+  PLM_REQUIRE(src && dst && dst_t, "plm_cast_f32_bf16_t: null pointer");
+  PLM_REQUIRE(rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0, "plm_cast_f32_bf16_t: rows=%ld cols=%ld must be positive multiples of 8",
+              (long)rows, (long)cols);
+  dim3 grid((unsigned)plm_cdiv(cols, 64), (unsigned)plm_cdiv(rows, 64));
+  hipLaunchKernelGGL(cast_f32_bf16_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_t, rows, cols);
+  PLM_CHECK_LAUNCH("plm_cast_f32_bf16_t");
+  return PLM_OK;
+}
+
+// ===========================================================================
+// embedding  (models/transformer.py:94,110)
+// ===========================================================================
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ W,
+                                                        float* __restrict__ out, int64_t M, int d, int64_t V) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // host validates ids; clamp keeps the kernel memory-safe
+  const float* src = W + id * d;
+  float* dst = out + row * d;
+  for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<f32x4_t*>(dst + c) = *reinterpret_cast<const f32x4_t*>(src + c);
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                        float* __restrict__ dW, int64_t M, int d, int64_t V) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int64_t id = ids[row];
+  if (id < 0 || id >= V) return;
+  const float* src = dout + row * d;
+  float* dst = dW + id * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + c);
+    unsafeAtomicAdd(dst + c + 0, v[0]);
+    unsafeAtomicAdd(dst + c + 1, v[1]);
+    unsafeAtomicAdd(dst + c + 2, v[2]);
+    unsafeAtomicAdd(dst + c + 3, v[3]);
+  }
+}
+
+extern "C" int plm_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t M, int64_t d, int64_t V, void* stream) {
+  PLM_REQUIRE(ids && W && out, "plm_embed_fwd: null pointer");
+  PLM_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && V > 0, "plm_embed_fwd: bad shape M=%ld d=%ld V=%ld", (long)M, (long)d, (long)V);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)plm_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ids, W, out, M, (int)d, V);
+  PLM_CHECK_LAUNCH("plm_embed_fwd");
+  return PLM_OK;
+}
+
+extern "C" int plm_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t M, int64_t d, int64_t V, void* stream) {
+  PLM_REQUIRE(ids && dout && dW, "plm_embed_bwd: null pointer");
+  PLM_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && V > 0, "plm_embed_bwd: bad shape M=%ld d=%ld V=%ld", (long)M, (long)d, (long)V);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)plm_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ids, dout, dW, M, (int)d, V);
+  PLM_CHECK_LAUNCH("plm_embed_bwd");
+  return PLM_OK;
+}
+
+// ===========================================================================
+// RMSNorm (+ residual add)   (models/components.py:16-28, transformer.py:81-82)
+// One wave per row; the row lives in registers (NCH float4 per lane, d <= 256*NCH).
+// ===========================================================================
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ branch,
+                                                          float* __restrict__ xout, const float* __restrict__ w,
+                                                          uint16_t* __restrict__ y, float* __restrict__ rstd, int64_t M,
+                                                          int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = d >> 2;
+  const float* xr = x + row * d;
+  f32x4_t v[NCH];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (c < nvec) {
+      v[i] = *reinterpret_cast<const f32x4_t*>(xr + c * 4);
+      if (branch) {
+        const bf16x4_t b = ld_bf16x4(branch + row * d + c * 4);
+        v[i][0] += bf2f(b[0]); v[i][1] += bf2f(b[1]); v[i][2] += bf2f(b[2]); v[i][3] += bf2f(b[3]);
+      }
+      if (xout) *reinterpret_cast<f32x4_t*>(xout + row * d + c * 4) = v[i];
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(w + c * 4);
+      bf16x4_t o;
+      o[0] = f2bf((v[i][0] * r) * wv[0]);
+      o[1] = f2bf((v[i][1] * r) * wv[1]);
+      o[2] = f2bf((v[i][2] * r) * wv[2]);
+      o[3] = f2bf((v[i][3] * r) * wv[3]);
+      st_bf16x4(y + row * d + c * 4, o);
+    }
+  }
+  if (lane == 0) rstd[row] = r;
+}
+
+#define PLM_RMS_BWD_MAX_BLOCKS 1024
+
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gin, float* __restrict__ dx,
+                                                          uint16_t* __restrict__ dx_bf16, float* __restrict__ dw_partial,
+                                                          int64_t M, int d) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = d >> 2;
+  const float inv_d = 1.f / (float)d;
+  f32x4_t wv[NCH], dwacc[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    wv[i] = (c < nvec) ? *reinterpret_cast<const f32x4_t*>(w + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    dwacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    f32x4_t a[NCH], xv[NCH];
+    float dot = 0.f;
+    const float r = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      a[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      xv[i] = a[i];
+      if (c < nvec) {
+        const bf16x4_t g = ld_bf16x4(dy + row * d + c * 4);
+        xv[i] = *reinterpret_cast<const f32x4_t*>(x + row * d + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gf = bf2f(g[e]);
+          dwacc[i][e] += gf * (xv[i][e] * r);
+          a[i][e] = gf * wv[i][e];
+          dot += a[i][e] * xv[i][e];
+        }
+      }
+    }
+    dot = wave_sum(dot);
+    const float coef = dot * r * r * r * inv_d;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = r * a[i][e] - xv[i][e] * coef;
+        if (gin) {
+          const f32x4_t gi = *reinterpret_cast<const f32x4_t*>(gin + row * d + c * 4);
+          o += gi;
+        }
+        *reinterpret_cast<f32x4_t*>(dx + row * d + c * 4) = o;
+        if (dx_bf16) {
+          bf16x4_t ob;
+          ob[0] = f2bf(o[0]); ob[1] = f2bf(o[1]); ob[2] = f2bf(o[2]); ob[3] = f2bf(o[3]);
+          st_bf16x4(dx_bf16 + row * d + c * 4, ob);
+        }
+      }
+    }
+  }
+  // block-level reduction of the 4 waves' dw partials
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) *reinterpret_cast<f32x4_t*>(red + wave * d + c * 4) = dwacc[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    dw_partial[(int64_t)blockIdx.x * d + c] = red[c] + red[d + c] + red[2 * d + c] + red[3 * d + c];
+  }
+}
+
+extern "C" int64_t plm_rmsnorm_bwd_blocks(int64_t M) {
+  const int64_t b = plm_cdiv(M, 4);
+  return b < PLM_RMS_BWD_MAX_BLOCKS ? b : PLM_RMS_BWD_MAX_BLOCKS;
+}
+
+extern "C" int plm_rmsnorm_fwd(const float* x, const uint16_t* branch, float* xout, const float* w, uint16_t* y, float* rstd,
+                               int64_t M, int64_t d, float eps, void* stream) {
+  PLM_REQUIRE(x && w && y && rstd, "plm_rmsnorm_fwd: null pointer");
+  PLM_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "plm_rmsnorm_fwd: unsupported shape M=%ld d=%ld (d %% 4 == 0, d <= 2048)", (long)M, (long)d);
+  const dim3 grid((unsigned)plm_cdiv(M, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d <= 256) hipLaunchKernelGGL(rmsnorm_fwd_kernel<1>, grid, block, 0, s, x, branch, xout, w, y, rstd, M, (int)d, eps);
+  else if (d <= 768) hipLaunchKernelGGL(rmsnorm_fwd_kernel<3>, grid, block, 0, s, x, branch, xout, w, y, rstd, M, (int)d, eps);
+  else if (d <= 1024) hipLaunchKernelGGL(rmsnorm_fwd_kernel<4>, grid, block, 0, s, x, branch, xout, w, y, rstd, M, (int)d, eps);
+  else hipLaunchKernelGGL(rmsnorm_fwd_kernel<8>, grid, block, 0, s, x, branch, xout, w, y, rstd, M, (int)d, eps);
+  PLM_CHECK_LAUNCH("plm_rmsnorm_fwd");
+  return PLM_OK;
+}
+
+extern "C" int plm_rmsnorm_bwd(const uint16_t* dy, const float* x, const float* w, const float* rstd, const float* gin,
+                               float* dx, uint16_t* dx_bf16, float* dw_partial, int64_t M, int64_t d, void* stream) {
+  PLM_REQUIRE(dy && x && w && rstd && dx && dw_partial, "plm_rmsnorm_bwd: null pointer");
+  PLM_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "plm_rmsnorm_bwd: unsupported shape M=%ld d=%ld", (long)M, (long)d);
+  const dim3 grid((unsigned)plm_rmsnorm_bwd_blocks(M)), block(256);
+  const size_t smem = (size_t)4 * d * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (d <= 256) hipLaunchKernelGGL(rmsnorm_bwd_kernel<1>, grid, block, smem, s, dy, x, w, rstd, gin, dx, dx_bf16, dw_partial, M, (int)d);
+  else if (d <= 768) hipLaunchKernelGGL(rmsnorm_bwd_kernel<3>, grid, block, smem, s, dy, x, w, rstd, gin, dx, dx_bf16, dw_partial, M, (int)d);
+  else if (d <= 1024) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, block, smem, s, dy, x, w, rstd, gin, dx, dx_bf16, dw_partial, M, (int)d);
+  else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, block, smem, s, dy, x, w, rstd, gin, dx, dx_bf16, dw_partial, M, (int)d);
+  PLM_CHECK_LAUNCH("plm_rmsnorm_bwd");
+  return PLM_OK;
+}
+
+// out[j] (+)= sum_r part[r][j]   — rows <= a few thousand, one thread per column
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows,
+                                                     int64_t cols, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t r = 0;
+  for (; r + 3 < rows; r += 4) {
+    s0 += part[r * cols + c];
+    s1 += part[(r + 1) * cols + c];
+    s2 += part[(r + 2) * cols + c];
+    s3 += part[(r + 3) * cols + c];
+  }
+  for (; r < rows; ++r) s0 += part[r * cols + c];
+  const float s = (s0 + s1) + (s2 + s3);
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int plm_colsum_f32(const float* part, float* out, int64_t rows, int64_t cols, int accumulate, void* stream) {
+  PLM_REQUIRE(part && out && rows > 0 && cols > 0, "plm_colsum_f32: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)plm_cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, part, out, rows, cols, accumulate);
+  PLM_CHECK_LAUNCH("plm_colsum_f32");
+  return PLM_OK;
+}
+
+// ===========================================================================
+// SwiGLU gate   (models/components.py:55-56) — bf16 autograd chain of the reference:
+//   s = bf16(silu(x)) ; out = bf16(s * z)
+//   ds = bf16(dout * z) ; dz = bf16(dout * s) ; dx = bf16(ds * sig * (1 + x * (1 - sig)))
+// ===========================================================================
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ out, int64_t M,
+                                                         int64_t h) {
+  const int64_t hv = h >> 3, total = M * hv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t m = i / hv, c = (i - m * hv) * 8;
+    const bf16x8_t xv = ld_bf16x8(u + m * 2 * h + c);
+    const bf16x8_t zv = ld_bf16x8(u + m * 2 * h + h + c);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xf = bf2f(xv[e]);
+      const bf16_t s = f2bf(xf * sigmoidf_(xf));
+      o[e] = f2bf(bf2f(s) * bf2f(zv[e]));
+    }
+    st_bf16x8(out + m * h + c, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ u,
+                                                         uint16_t* __restrict__ du, int64_t M, int64_t h) {
+  const int64_t hv = h >> 3, total = M * hv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t m = i / hv, c = (i - m * hv) * 8;
+    const bf16x8_t xv = ld_bf16x8(u + m * 2 * h + c);
+    const bf16x8_t zv = ld_bf16x8(u + m * 2 * h + h + c);
+    const bf16x8_t gv = ld_bf16x8(dout + m * h + c);
+    bf16x8_t dxo, dzo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xf = bf2f(xv[e]), zf = bf2f(zv[e]), gf = bf2f(gv[e]);
+      const float sig = sigmoidf_(xf);
+      const bf16_t s = f2bf(xf * sig);
+      const bf16_t ds = f2bf(gf * zf);
+      dzo[e] = f2bf(gf * bf2f(s));
+      dxo[e] = f2bf(bf2f(ds) * (sig * (1.f + xf * (1.f - sig))));
+    }
+    st_bf16x8(du + m * 2 * h + c, dxo);
+    st_bf16x8(du + m * 2 * h + h + c, dzo);
+  }
+}
+
+static int elementwise_grid(int64_t items) {
+  const int64_t b = plm_cdiv(items, 256);
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+extern "C" int plm_swiglu_fwd(const uint16_t* u, uint16_t* out, int64_t M, int64_t h, void* stream) {
+  PLM_REQUIRE(u && out && M > 0 && h > 0 && h % 8 == 0, "plm_swiglu_fwd: bad arguments (h %% 8 == 0)");
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(elementwise_grid(M * (h / 8))), dim3(256), 0, (hipStream_t)stream, u, out, M, h);
+  PLM_CHECK_LAUNCH("plm_swiglu_fwd");
+  return PLM_OK;
+}
+
+extern "C" int plm_swiglu_bwd(const uint16_t* dout, const uint16_t* u, uint16_t* du, int64_t M, int64_t h, void* stream) {
+  PLM_REQUIRE(dout && u && du && M > 0 && h > 0 && h % 8 == 0, "plm_swiglu_bwd: bad arguments (h %% 8 == 0)");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(elementwise_grid(M * (h / 8))), dim3(256), 0, (hipStream_t)stream, dout, u, du, M, h);
+  PLM_CHECK_LAUNCH("plm_swiglu_bwd");
+  return PLM_OK;
+}
+
+// ===========================================================================
+// small deterministic reductions
+// ===========================================================================
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float t = (threadIdx.x < nw) ? sh[threadIdx.x] : 0.f;
+  if (wave == 0) t = wave_sum(t);
+  __syncthreads();
+  if (threadIdx.x == 0) sh[0] = t;
+  __syncthreads();
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+extern "C" int plm_mean_f32(const float* x, float* out, int64_t n, void* stream) {
+  PLM_REQUIRE(x && out && n > 0, "plm_mean_f32: bad arguments");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, out, n);
+  PLM_CHECK_LAUNCH("plm_mean_f32");
+  return PLM_OK;
+}
+
+__global__ __launch_bounds__(1024) void sumsq_stage1_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ scratch) {
+  __shared__ float sh[16];
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < nvec; i += stride) {
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += 1024) s += x[i] * x[i];
+  }
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(1024) void sum_stage2_kernel(const float* __restrict__ scratch, int n, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += scratch[i];
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+extern "C" int plm_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, void* stream) {
+  PLM_REQUIRE(x && scratch && out && n > 0, "plm_sumsq_f32: bad arguments");
+  PLM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "plm_sumsq_f32: x must be 16-byte aligned");
+  int64_t blocks = plm_cdiv(plm_cdiv(n, 4), 1024);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_stage1_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, x, n, scratch);
+  hipLaunchKernelGGL(sum_stage2_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scratch, (int)blocks, out);
+  PLM_CHECK_LAUNCH("plm_sumsq_f32");
+  return PLM_OK;
+}
+
+// ===========================================================================
+// AdamW on a flat fp32 span  (torch.optim.AdamW semantics; optim/init_optim.py:14-21)
+// ===========================================================================
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
+  const float cs = clip ? *clip : 1.f;
+  const float step = lr / bc1;
+  const float decay = 1.f - lr * wd;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * cs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] * decay - step * (mi / denom);
+  }
+}
+
+extern "C" int plm_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float bc1, float bc2, const float* clip_coef_dev, void* stream) {
+  PLM_REQUIRE(p && g && m && v && n > 0, "plm_adamw_f32: bad arguments");
+  hipLaunchKernelGGL(adamw_kernel, dim3(elementwise_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2), clip_coef_dev);
+  PLM_CHECK_LAUNCH("plm_adamw_f32");
+  return PLM_OK;
+}

@@ -1,0 +1,388 @@
+// bf16 MFMA GEMMs for gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+//   nt : C[M,N] = alpha * A[M,K] · B[N,K]^T      (y = x W^T ; dX = dY (W^T)^T with the transposed weight copy)
+//   tn : C[M,N] (+)= alpha * A[K,M]^T · B[K,N]    (dW = dY^T X, contraction over the token rows)
+//
+// Structure (both): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave a 64x64
+// sub-tile = 2x2 MFMA 32x32 accumulators), BK = 64, operands staged global -> registers -> LDS with the
+// next tile's global loads in flight during the MFMAs of the current one (one LDS buffer, two barriers
+// per K-step, ~3 workgroups per CU so other workgroups cover the barrier bubbles).
+//
+// nt LDS image: [128 rows][64 k] bf16 (128-byte rows); the 16-byte chunk index is XOR-ed with
+//   (row>>1)&7 so the sixteen lanes of a ds_read_b128 service group (16 distinct rows mod 16, same
+//   k-chunk) hit sixteen different 16-byte slots of the 256-byte bank row: conflict-free.
+// tn LDS image: [8 column-subtiles][64 k-rows][16 cols] (32-byte rows, sub-tile stride 2048+128 B) read
+//   with ds_read_b64_tr_b16, which hands lane t column t of a [4 k][16 col] block: the MFMA operand
+//   with k = token row.  A 32-lane half covers two sub-tiles 128 B apart mod 256: conflict-free.
+//
+// Workgroup -> tile map: XCD-aware remap (each XCD gets a contiguous id range) and grouped
+// rasterisation (GROUP_M row-panels x all column tiles) so A panels and B tiles are reused from L2.
+#include "plm_device.h"
+
+#define GBM 128
+#define GBN 128
+#define GBK 64
+#define GROUP_M 8
+#define TN_SUB_STRIDE 2176  // 64 rows * 32 B + 128 B pad
+
+__device__ __forceinline__ void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int pid = xcd_remap(bid, nwg);
+  const int group_size = GROUP_M * tiles_n;
+  const int group = pid / group_size;
+  const int first_m = group * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  const int in_group = pid - group * group_size;
+  tm = first_m + in_group % gm;
+  tn = in_group / gm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) {  // byte offset of a 16-byte chunk
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <bool OUT_F32, bool ACCUM>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                      const uint16_t* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
+                                                      int64_t ldc, int M, int N, int K, const float* __restrict__ alpha_dev,
+                                                      int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * GBM * GBK * 2];
+  char* sA = smem;
+  char* sB = smem + GBM * GBK * 2;
+
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // staging assignment: 4 chunks of A and 4 of B per thread
+  int ld_row[4], ld_chunk[4];
+  const uint16_t* a_ptr[4];
+  const uint16_t* b_ptr[4];
+  bool a_ok[4], b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + t;
+    ld_row[i] = idx >> 3;
+    ld_chunk[i] = idx & 7;
+    a_ok[i] = (m0 + ld_row[i]) < M;
+    b_ok[i] = (n0 + ld_row[i]) < N;
+    a_ptr[i] = A + (int64_t)(m0 + ld_row[i]) * lda + ld_chunk[i] * 8;
+    b_ptr[i] = B + (int64_t)(n0 + ld_row[i]) * ldb + ld_chunk[i] * 8;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t ra[4], rb[4];
+  auto g_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool kin = (k0 + ld_chunk[i] * 8) < K;
+      ra[i] = (a_ok[i] && kin) ? ld_bf16x8(a_ptr[i] + k0) : zero_bf16x8();
+      rb[i] = (b_ok[i] && kin) ? ld_bf16x8(b_ptr[i] + k0) : zero_bf16x8();
+    }
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = nt_lds_off(ld_row[i], ld_chunk[i]);
+      *reinterpret_cast<bf16x8_t*>(sA + off) = ra[i];
+      *reinterpret_cast<bf16x8_t*>(sB + off) = rb[i];
+    }
+  };
+
+  const int nk = (K + GBK - 1) / GBK;
+  g_load(0);
+  s_store();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) g_load((kt + 1) * GBK);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sA + nt_lds_off(wm * 64 + i * 32 + l31, ks * 2 + hi));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sB + nt_lds_off(wn * 64 + i * 32 + l31, ks * 2 + hi));
+      }
+      // D'[n][m] = sum_k B[n][k] A[m][k]: the lane ends up owning one C row (m) and runs of 4 consecutive n
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bfr[j], af[i], acc[i][j]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      s_store();
+      __syncthreads();
+    }
+  }
+
+  const float alpha = alpha_dev ? *alpha_dev : 1.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+        if (n >= N) continue;
+        f32x4_t v = {acc[i][j][4 * g + 0] * alpha, acc[i][j][4 * g + 1] * alpha, acc[i][j][4 * g + 2] * alpha,
+                     acc[i][j][4 * g + 3] * alpha};
+        if (OUT_F32) {
+          float* dst = reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n;
+          if (n + 3 < N) {
+            if (ACCUM) v += *reinterpret_cast<const f32x4_t*>(dst);
+            *reinterpret_cast<f32x4_t*>(dst) = v;
+          } else {
+            for (int e = 0; e < 4 && n + e < N; ++e) dst[e] = ACCUM ? dst[e] + v[e] : v[e];
+          }
+        } else {
+          uint16_t* dst = reinterpret_cast<uint16_t*>(Cv) + (int64_t)m * ldc + n;
+          bf16x4_t o;
+          o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+          if (n + 3 < N) {
+            st_bf16x4(dst, o);
+          } else {
+            for (int e = 0; e < 4 && n + e < N; ++e) reinterpret_cast<bf16_t*>(dst)[e] = o[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream) {
+  PLM_REQUIRE(A && B && C, "plm_gemm_bf16_nt: null pointer");
+  PLM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "plm_gemm_bf16_nt: bad shape M=%ld N=%ld K=%ld",
+              (long)M, (long)N, (long)K);
+  PLM_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "plm_gemm_bf16_nt: K, lda, ldb must be multiples of 8 and ldc of 4 (K=%ld lda=%ld ldb=%ld ldc=%ld)",
+              (long)K, (long)lda, (long)ldb, (long)ldc);
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) == 0,
+              "plm_gemm_bf16_nt: base pointers must be 16-byte aligned");
+  PLM_REQUIRE(c_dtype == 0 || c_dtype == 1, "plm_gemm_bf16_nt: c_dtype must be 0 (bf16) or 1 (fp32)");
+  PLM_REQUIRE(!(accumulate && c_dtype == 0), "plm_gemm_bf16_nt: accumulate needs an fp32 C");
+  const int tiles_m = (int)plm_cdiv(M, GBM), tiles_n = (int)plm_cdiv(N, GBN);
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (c_dtype == 0)
+    hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n);
+  else if (accumulate)
+    hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n);
+  PLM_CHECK_LAUNCH("plm_gemm_bf16_nt");
+  return PLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN   C[i][j] = sum_k A[k][i] B[k][j]
+// ---------------------------------------------------------------------------------------------
+// MODE 0: C = alpha*acc   MODE 1: C += alpha*acc   MODE 2: raw partial into a split-K slab (ld = N)
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                      const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                      int64_t ldc, int M, int N, int K, int kchunk,
+                                                      const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8 * TN_SUB_STRIDE];
+  char* sA = smem;
+  char* sB = smem + 8 * TN_SUB_STRIDE;
+
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int i0 = tm * GBM, j0 = tn * GBN;
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
+
+  int ld_krow[4], ld_off[4];
+  const uint16_t* a_ptr[4];
+  const uint16_t* b_ptr[4];
+  bool a_ok[4], b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + t;
+    const int u = idx & 7, cl = u & 3, rl = u >> 2, rest = idx >> 3;
+    const int c = (rest & 3) * 4 + cl;           // 16-byte chunk along the 128 columns
+    ld_krow[i] = ((rest >> 2) << 1) | rl;        // 0..63
+    ld_off[i] = (c >> 1) * TN_SUB_STRIDE + ld_krow[i] * 32 + (c & 1) * 16;
+    a_ok[i] = (i0 + c * 8) < M;
+    b_ok[i] = (j0 + c * 8) < N;
+    a_ptr[i] = A + (int64_t)ld_krow[i] * lda + i0 + c * 8;
+    b_ptr[i] = B + (int64_t)ld_krow[i] * ldb + j0 + c * 8;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t ra[4], rb[4];
+  auto g_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool kin = (k0 + ld_krow[i]) < kend;
+      ra[i] = (a_ok[i] && kin) ? ld_bf16x8(a_ptr[i] + (int64_t)k0 * lda) : zero_bf16x8();
+      rb[i] = (b_ok[i] && kin) ? ld_bf16x8(b_ptr[i] + (int64_t)k0 * ldb) : zero_bf16x8();
+    }
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<bf16x8_t*>(sA + ld_off[i]) = ra[i];
+      *reinterpret_cast<bf16x8_t*>(sB + ld_off[i]) = rb[i];
+    }
+  };
+  // transpose-read of one 32-column operand block starting at tile column cb, k-step ks
+  auto tr_frag = [&](const char* base, int cb, int ks) -> bf16x8_t {
+    const char* p = base + ((cb >> 4) + ib) * TN_SUB_STRIDE + (ks * 16 + hi * 8 + (t16 >> 2)) * 32 + (t16 & 3) * 8;
+    const s16x4_t lo = lds_read_tr16(p);
+    const s16x4_t hh = lds_read_tr16(p + 4 * 32);
+    return join_tr(lo, hh);
+  };
+
+  const int nk = (kend - kbeg + GBK - 1) / GBK;
+  if (nk > 0) {
+    g_load(kbeg);
+    s_store();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) g_load(kbeg + (kt + 1) * GBK);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = tr_frag(sA, wm * 64 + i * 32, ks);
+        bfr[i] = tr_frag(sB, wn * 64 + i * 32, ks);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      s_store();
+      __syncthreads();
+    }
+  }
+
+  const float alpha = (MODE != 2 && alpha_dev) ? *alpha_dev : 1.f;
+  float* out = (MODE == 2) ? C + (int64_t)blockIdx.y * M * N : C;
+  const int64_t ld = (MODE == 2) ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + mfma32_row(r, hi);
+        if (row >= M) continue;
+        float* dst = out + (int64_t)row * ld + col;
+        const float v = acc[i][j][r] * alpha;
+        *dst = (MODE == 1) ? *dst + v : v;
+      }
+    }
+  }
+}
+
+// C (+)= alpha * sum_s slab[s]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc, int M,
+                                                            int N, int splits, int accumulate,
+                                                            const float* __restrict__ alpha_dev) {
+  const float alpha = alpha_dev ? *alpha_dev : 1.f;
+  const int64_t nv = (int64_t)M * (N >> 2);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int nq = N >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    const int64_t row = i / nq;
+    const int col = (int)(i - row * nq) * 4;
+    f32x4_t s = *reinterpret_cast<const f32x4_t*>(ws + row * N + col);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4_t*>(ws + (int64_t)k * M * N + row * N + col);
+    s *= alpha;
+    float* dst = C + row * ldc + col;
+    if (accumulate) s += *reinterpret_cast<const f32x4_t*>(dst);
+    *reinterpret_cast<f32x4_t*>(dst) = s;
+  }
+}
+
+static int tn_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = plm_cdiv(M, GBM) * plm_cdiv(N, GBN);
+  if (tiles >= 384) return 1;
+  int64_t s = plm_cdiv(768, tiles);
+  const int64_t max_by_k = K / 512 > 0 ? K / 512 : 1;  // keep >= 512 contraction rows per slab
+  if (s > max_by_k) s = max_by_k;
+  if (s > 32) s = 32;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int s = tn_splits(M, N, K);
+  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                                int64_t N, int64_t K, int accumulate, const float* alpha_dev, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  PLM_REQUIRE(A && B && C, "plm_gemm_bf16_tn: null pointer");
+  PLM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "plm_gemm_bf16_tn: bad shape M=%ld N=%ld K=%ld",
+              (long)M, (long)N, (long)K);
+  PLM_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
+              "plm_gemm_bf16_tn: M, N, lda, ldb must be multiples of 8 and ldc of 4 (M=%ld N=%ld lda=%ld ldb=%ld ldc=%ld)", (long)M, (long)N,
+              (long)lda, (long)ldb, (long)ldc);
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) == 0,
+              "plm_gemm_bf16_tn: base pointers must be 16-byte aligned");
+  const int tiles_m = (int)plm_cdiv(M, GBM), tiles_n = (int)plm_cdiv(N, GBN);
+  const int splits = tn_splits(M, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 block(256);
+  if (splits == 1) {
+    const dim3 grid((unsigned)(tiles_m * tiles_n), 1);
+    if (accumulate)
+      hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K, alpha_dev, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K, alpha_dev, tiles_m, tiles_n);
+    PLM_CHECK_LAUNCH("plm_gemm_bf16_tn");
+    return PLM_OK;
+  }
+  const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    plm_set_error("plm_gemm_bf16_tn: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    return PLM_E_WORKSPACE;
+  }
+  PLM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "plm_gemm_bf16_tn: workspace must be 16-byte aligned");
+  const int kchunk = (int)(plm_cdiv(plm_cdiv(K, splits), GBK) * GBK);
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, block, 0, s, A, lda, B, ldb, (float*)workspace, (int64_t)N, (int)M, (int)N, (int)K, kchunk,
+                     (const float*)nullptr, tiles_m, tiles_n);
+  const int64_t nv = M * (N / 4);
+  int64_t rb = plm_cdiv(nv, 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), block, 0, s, (const float*)workspace, C, ldc, (int)M, (int)N, splits, accumulate,
+                     alpha_dev);
+  PLM_CHECK_LAUNCH("plm_gemm_bf16_tn");
+  return PLM_OK;
+}

@@ -1,0 +1,63 @@
+// Error plumbing, version, and the hardware-semantics probes used by the GPU tests.
+#include <stdarg.h>
+#include <string.h>
+
+#include "plm_device.h"
+
+static thread_local char g_err[512] = "";
+
+void plm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* plm_last_error_string(void) { return g_err; }
+extern "C" int plm_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------
+// probe: what does ds_read_b64_tr_b16 deliver?  LDS holds 0,1,2,...; lane l reads at byte 8*l.
+// ---------------------------------------------------------------------------
+__global__ void probe_tr16_kernel(int32_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[256];
+  const int l = threadIdx.x;
+  for (int i = l; i < 256; i += 64) lds[i] = (uint16_t)i;
+  __syncthreads();
+  const s16x4_t v = lds_read_tr16(reinterpret_cast<const char*>(lds) + 8 * l);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (int32_t)(uint16_t)v[j];
+}
+
+extern "C" int plm_probe_ds_read_tr16(int32_t* out, void* stream) {
+  PLM_REQUIRE(out, "plm_probe_ds_read_tr16: null pointer");
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  PLM_CHECK_LAUNCH("plm_probe_ds_read_tr16");
+  return PLM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// probe: operand / accumulator layout of v_mfma_f32_32x32x16_bf16 as mfma32() documents it
+// ---------------------------------------------------------------------------
+__global__ void probe_mfma32_kernel(const float* A, const float* B, float* out) {
+  const int l = threadIdx.x, l31 = l & 31, hi = l >> 5;
+  bf16x8_t a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = f2bf(A[l31 * 16 + hi * 8 + e]);    // A[i][k], row-major [32][16]
+    b[e] = f2bf(B[(hi * 8 + e) * 32 + l31]);  // B[k][j], row-major [16][32]
+  }
+  f32x16_t c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  c = mfma32(a, b, c);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[mfma32_row(r, hi) * 32 + l31] = c[r];
+}
+
+extern "C" int plm_probe_mfma32(const float* A, const float* B, float* out, void* stream) {
+  PLM_REQUIRE(A && B && out, "plm_probe_mfma32: null pointer");
+  hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, out);
+  PLM_CHECK_LAUNCH("plm_probe_mfma32");
+  return PLM_OK;
+}

@@ -1,0 +1,104 @@
+// Shared device/host helpers for the gfx950 kernels of libplainlm_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/plainlm_hip.h"
+
+// ---------------------------------------------------------------------------
+// host-side error plumbing
+// ---------------------------------------------------------------------------
+void plm_set_error(const char* fmt, ...);
+
+#define PLM_REQUIRE(cond, ...)       \
+  do {                               \
+    if (!(cond)) {                   \
+      plm_set_error(__VA_ARGS__);    \
+      return PLM_E_INVALID;          \
+    }                                \
+  } while (0)
+
+#define PLM_CHECK_LAUNCH(name)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      plm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return PLM_E_HIP;                                                          \
+    }                                                                            \
+  } while (0)
+
+static inline int64_t plm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// device-side types
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define PLM_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32, RNE
+
+// 16-byte global load / store of 8 bf16
+__device__ __forceinline__ bf16x8_t ld_bf16x8(const uint16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+__device__ __forceinline__ void st_bf16x8(uint16_t* p, bf16x8_t v) { *reinterpret_cast<bf16x8_t*>(p) = v; }
+__device__ __forceinline__ bf16x4_t ld_bf16x4(const uint16_t* p) { return *reinterpret_cast<const bf16x4_t*>(p); }
+__device__ __forceinline__ void st_bf16x4(uint16_t* p, bf16x4_t v) { *reinterpret_cast<bf16x4_t*>(p) = v; }
+
+__device__ __forceinline__ bf16x8_t zero_bf16x8() {
+  u32x4_t z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, z);
+}
+
+// full-wave (64 lanes) reductions; every lane receives the result
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// v_mfma_f32_32x32x16_bf16:  D[i][j] += sum_k A[i][k] B[k][j]
+//   a: lane l holds A[i = l&31][k-slots (l>>5)*8 + 0..7]
+//   b: lane l holds B[k-slots (l>>5)*8 + 0..7][j = l&31]
+//   d: lane l reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+__device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// row (i) index of accumulator register r for lane-half hi in a 32x32 tile
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ds_read_b64_tr_b16: within each 16-lane group, lane t supplies the address of
+// 4 consecutive bf16 of row (t>>2), column chunk (t&3) of a [4 rows][16 cols] block
+// (any row stride) and receives column t of that block: out[j] = block[row j][col t].
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+__device__ __forceinline__ s16x4_t lds_read_tr16(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(lds_ptr));
+}
+__device__ __forceinline__ bf16x8_t join_tr(s16x4_t lo, s16x4_t hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive ids on one XCD
+// (hardware places workgroup b on XCD b % 8) so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}

@@ -1,0 +1,262 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with torch (the caching
+allocator owns all memory), pass raw device pointers + the current HIP stream.
+
+Every function here launches hand-written gfx950 kernels; none has a torch fallback.
+"""
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+  return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need(t, dtype, name, dim=None):
+  if not t.is_cuda:
+    raise RuntimeError(f'{name}: tensor must live on the GPU (plainlm_amd has no CPU path)')
+  if t.dtype != dtype:
+    raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+  if not t.is_contiguous():
+    raise ValueError(f'{name}: tensor must be contiguous')
+  if dim is not None and t.dim() != dim:
+    raise ValueError(f'{name}: expected {dim} dims, got {t.dim()}')
+  return t
+
+
+# ---- casts ------------------------------------------------------------------
+def cast_bf16(src, out=None):
+  _need(src, F32, 'cast_bf16.src')
+  out = torch.empty(src.shape, dtype=BF16, device=src.device) if out is None else out
+  _lib.check(_lib.load().plm_cast_f32_bf16(_p(src), _p(out), src.numel(), _stream()), 'plm_cast_f32_bf16')
+  return out
+
+
+def cast_bf16_t(src, out=None, out_t=None):
+  """src fp32 [R, C] -> (bf16 [R, C], bf16 [C, R])."""
+  _need(src, F32, 'cast_bf16_t.src', 2)
+  R, Cc = src.shape
+  out = torch.empty((R, Cc), dtype=BF16, device=src.device) if out is None else out
+  out_t = torch.empty((Cc, R), dtype=BF16, device=src.device) if out_t is None else out_t
+  _lib.check(_lib.load().plm_cast_f32_bf16_t(_p(src), _p(out), _p(out_t), R, Cc, _stream()), 'plm_cast_f32_bf16_t')
+  return out, out_t
+
+
+# ---- embedding ----------------------------------------------------------------
+def embed_fwd(ids, W):
+  _need(ids, torch.int64, 'embed_fwd.ids')
+  _need(W, F32, 'embed_fwd.W', 2)
+  M = ids.numel()
+  out = torch.empty((M, W.shape[1]), dtype=F32, device=W.device)
+  _lib.check(_lib.load().plm_embed_fwd(_p(ids), _p(W), _p(out), M, W.shape[1], W.shape[0], _stream()), 'plm_embed_fwd')
+  return out
+
+
+def embed_bwd(ids, dout, dW):
+  """dW[ids[m]] += dout[m]  (dW must hold the value to accumulate onto)."""
+  _need(ids, torch.int64, 'embed_bwd.ids')
+  _need(dout, F32, 'embed_bwd.dout', 2)
+  _need(dW, F32, 'embed_bwd.dW', 2)
+  _lib.check(_lib.load().plm_embed_bwd(_p(ids), _p(dout), _p(dW), ids.numel(), dW.shape[1], dW.shape[0], _stream()),
+             'plm_embed_bwd')
+  return dW
+
+
+# ---- rmsnorm --------------------------------------------------------------------
+def rmsnorm_fwd(x, w, eps, branch=None, write_xout=False):
+  """returns (xout fp32 or None, y bf16, rstd fp32).  r = x + branch; y = bf16(r * rstd * w)."""
+  _need(x, F32, 'rmsnorm_fwd.x', 2)
+  _need(w, F32, 'rmsnorm_fwd.w', 1)
+  M, d = x.shape
+  if branch is not None:
+    _need(branch, BF16, 'rmsnorm_fwd.branch', 2)
+  xout = torch.empty_like(x) if (write_xout or branch is not None) else None
+  y = torch.empty((M, d), dtype=BF16, device=x.device)
+  rstd = torch.empty((M,), dtype=F32, device=x.device)
+  _lib.check(_lib.load().plm_rmsnorm_fwd(_p(x), _p(branch), _p(xout), _p(w), _p(y), _p(rstd), M, d, float(eps), _stream()),
+             'plm_rmsnorm_fwd')
+  return xout, y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, gin=None, want_bf16=False, dw_out=None, dw_accumulate=False):
+  """returns (dx fp32, dx_bf16 or None, dw fp32[d]).  dx = gin + d(rmsnorm)."""
+  _need(dy, BF16, 'rmsnorm_bwd.dy', 2)
+  _need(x, F32, 'rmsnorm_bwd.x', 2)
+  M, d = x.shape
+  lib = _lib.load()
+  if gin is not None:
+    _need(gin, F32, 'rmsnorm_bwd.gin', 2)
+  dx = torch.empty_like(x)
+  dxb = torch.empty((M, d), dtype=BF16, device=x.device) if want_bf16 else None
+  nblk = lib.plm_rmsnorm_bwd_blocks(M)
+  part = torch.empty((nblk, d), dtype=F32, device=x.device)
+  _lib.check(lib.plm_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(gin), _p(dx), _p(dxb), _p(part), M, d, _stream()),
+             'plm_rmsnorm_bwd')
+  if dw_out is None:
+    dw_out = torch.empty((d,), dtype=F32, device=x.device)
+    dw_accumulate = False
+  _lib.check(lib.plm_colsum_f32(_p(part), _p(dw_out), nblk, d, int(bool(dw_accumulate)), _stream()), 'plm_colsum_f32')
+  return dx, dxb, dw_out
+
+
+# ---- swiglu -----------------------------------------------------------------------
+def swiglu_fwd(u):
+  _need(u, BF16, 'swiglu_fwd.u', 2)
+  M, h2 = u.shape
+  out = torch.empty((M, h2 // 2), dtype=BF16, device=u.device)
+  _lib.check(_lib.load().plm_swiglu_fwd(_p(u), _p(out), M, h2 // 2, _stream()), 'plm_swiglu_fwd')
+  return out
+
+
+def swiglu_bwd(dout, u):
+  _need(dout, BF16, 'swiglu_bwd.dout', 2)
+  _need(u, BF16, 'swiglu_bwd.u', 2)
+  du = torch.empty_like(u)
+  _lib.check(_lib.load().plm_swiglu_bwd(_p(dout), _p(u), _p(du), u.shape[0], u.shape[1] // 2, _stream()), 'plm_swiglu_bwd')
+  return du
+
+
+# ---- GEMMs ------------------------------------------------------------------------
+def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None):
+  """C[M,N] = alpha * A[M,K] @ B[N,K]^T ; A, B bf16 (row stride may exceed K)."""
+  for t, n in ((A, 'A'), (B, 'B')):
+    if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
+      raise ValueError(f'gemm_nt.{n}: need a 2-D bf16 GPU tensor with unit inner stride')
+  M, K = A.shape
+  N = B.shape[0]
+  if B.shape[1] != K:
+    raise ValueError(f'gemm_nt: inner dims differ ({K} vs {B.shape[1]})')
+  if out is None:
+    out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+  if out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1:
+    raise ValueError('gemm_nt.out: bad shape/stride')
+  cd = {BF16: 0, F32: 1}[out.dtype]
+  if alpha is not None:
+    _need(alpha, F32, 'gemm_nt.alpha')
+  _lib.check(_lib.load().plm_gemm_bf16_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
+                                          int(bool(accumulate)), _p(alpha), _stream()), 'plm_gemm_bf16_nt')
+  return out
+
+
+_tn_ws = {}
+
+
+def _tn_workspace(nbytes, device):
+  """One grow-only split-K slab buffer per device (owned by torch's allocator)."""
+  buf = _tn_ws.get(device)
+  if buf is None or buf.numel() < nbytes:
+    buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    _tn_ws[device] = buf
+  return buf
+
+
+def gemm_tn(A, B, out=None, accumulate=False, alpha=None):
+  """C[M,N] (+)= alpha * A[K,M]^T @ B[K,N] ; A, B bf16, C fp32."""
+  for t, n in ((A, 'A'), (B, 'B')):
+    if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
+      raise ValueError(f'gemm_tn.{n}: need a 2-D bf16 GPU tensor with unit inner stride')
+  K, M = A.shape
+  N = B.shape[1]
+  if B.shape[0] != K:
+    raise ValueError(f'gemm_tn: contraction dims differ ({K} vs {B.shape[0]})')
+  if out is None:
+    out = torch.empty((M, N), dtype=F32, device=A.device)
+    accumulate = False
+  if out.dtype != F32 or out.shape != (M, N) or out.stride(1) != 1:
+    raise ValueError('gemm_tn.out: need fp32 [M, N] with unit inner stride')
+  lib = _lib.load()
+  nbytes = lib.plm_gemm_tn_workspace_bytes(M, N, K)
+  ws = _tn_workspace(nbytes, A.device) if nbytes else None
+  if alpha is not None:
+    _need(alpha, F32, 'gemm_tn.alpha')
+  _lib.check(lib.plm_gemm_bf16_tn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K,
+                                  int(bool(accumulate)), _p(alpha), _p(ws), nbytes, _stream()), 'plm_gemm_bf16_tn')
+  return out
+
+
+# ---- attention ----------------------------------------------------------------------
+def attn_fwd(qkv, rope_cos, rope_sin, B, T, nh, doc_start=None):
+  _need(qkv, BF16, 'attn_fwd.qkv', 2)
+  hd = qkv.shape[1] // (3 * nh)
+  _need(rope_cos, F32, 'attn_fwd.rope_cos', 2)
+  _need(rope_sin, F32, 'attn_fwd.rope_sin', 2)
+  if rope_cos.shape[0] < T or rope_cos.shape[1] != hd // 2:
+    raise ValueError('attn_fwd: RoPE table too short for T or wrong head_dim')
+  if doc_start is not None:
+    _need(doc_start, torch.int32, 'attn_fwd.doc_start', 2)
+  out = torch.empty((B * T, nh * hd), dtype=BF16, device=qkv.device)
+  lse = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
+  _lib.check(_lib.load().plm_attn_fwd(_p(qkv), _p(rope_cos), _p(rope_sin), _p(doc_start), _p(out), _p(lse), B, T, nh, hd,
+                                      _stream()), 'plm_attn_fwd')
+  return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, rope_cos, rope_sin, B, T, nh, doc_start=None):
+  _need(dout, BF16, 'attn_bwd.dout', 2)
+  hd = qkv.shape[1] // (3 * nh)
+  dqkv = torch.empty_like(qkv)
+  delta = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
+  _lib.check(_lib.load().plm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(rope_cos), _p(rope_sin), _p(doc_start),
+                                      _p(dqkv), _p(delta), B, T, nh, hd, _stream()), 'plm_attn_bwd')
+  return dqkv
+
+
+# ---- cross entropy --------------------------------------------------------------------
+def ce_fwd_bwd_(logits, targets, grad_scale):
+  """In place: logits <- (softmax - onehot) * grad_scale. Returns per-row losses fp32[M]."""
+  _need(logits, BF16, 'ce.logits', 2)
+  _need(targets, torch.int64, 'ce.targets', 1)
+  M, V = logits.shape
+  rows = torch.empty((M,), dtype=F32, device=logits.device)
+  _lib.check(_lib.load().plm_ce_fwd_bwd(_p(logits), _p(targets), _p(rows), M, V, float(grad_scale), _stream()), 'plm_ce_fwd_bwd')
+  return rows
+
+
+def mean(x):
+  _need(x, F32, 'mean.x')
+  out = torch.empty((), dtype=F32, device=x.device)
+  _lib.check(_lib.load().plm_mean_f32(_p(x), _p(out), x.numel(), _stream()), 'plm_mean_f32')
+  return out
+
+
+# ---- optimizer tail ---------------------------------------------------------------------
+def sumsq(x, scratch=None):
+  _need(x, F32, 'sumsq.x')
+  scratch = torch.empty(4096, dtype=F32, device=x.device) if scratch is None else scratch
+  out = torch.empty((), dtype=F32, device=x.device)
+  _lib.check(_lib.load().plm_sumsq_f32(_p(x), x.numel(), _p(scratch), _p(out), _stream()), 'plm_sumsq_f32')
+  return out
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None):
+  for t, n in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
+    _need(t, F32, 'adamw.' + n)
+  bc1 = 1.0 - beta1 ** step
+  bc2 = 1.0 - beta2 ** step
+  _lib.check(_lib.load().plm_adamw_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                                       _p(clip_coef), _stream()), 'plm_adamw_f32')
+
+
+# ---- probes -------------------------------------------------------------------------------
+def probe_ds_read_tr16():
+  out = torch.empty(256, dtype=torch.int32, device='cuda')
+  _lib.check(_lib.load().plm_probe_ds_read_tr16(_p(out), _stream()), 'plm_probe_ds_read_tr16')
+  return out.view(64, 4)
+
+
+def probe_mfma32(A, B):
+  _need(A, F32, 'probe.A', 2)
+  _need(B, F32, 'probe.B', 2)
+  out = torch.empty((32, 32), dtype=F32, device=A.device)
+  _lib.check(_lib.load().plm_probe_mfma32(_p(A), _p(B), _p(out), _stream()), 'plm_probe_mfma32')
+  return out

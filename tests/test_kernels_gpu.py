@@ -1,0 +1,346 @@
+"""Per-kernel parity tests on a real MI355X, through the C ABI, against fp32 references
+(the CPU oracle for the operators it defines; plain fp32 torch matmul for the GEMMs).
+
+Tolerances (stated per test) are relative to the reference tensor's max magnitude:
+  bf16 outputs  : 1.6e-2 (two bf16 roundings: 2^-8 each on inputs/intermediates + output)
+  fp32 outputs  : 2e-3 for bf16-input MFMA sums, 1e-5 for pure fp32 kernels
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from plainlm_amd import ops as _ops
+  return _ops
+
+
+def relerr(a, ref):
+  a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+  return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def close(a, ref, tol, what=''):
+  e = relerr(a, ref)
+  assert e <= tol, f'{what}: rel-to-max error {e:.3e} > {tol:.1e}'
+  return e
+
+
+def bf(x):
+  return x.to(torch.bfloat16)
+
+
+# --------------------------------------------------------------------------------------
+# hardware probes: the layout facts the MFMA kernels are built on
+# --------------------------------------------------------------------------------------
+def test_probe_ds_read_tr16(ops):
+  got = ops.probe_ds_read_tr16().cpu().numpy()
+  # lane l supplied address 8*l bytes over a linear uint16 ramp; within each 16-lane group the lane
+  # must receive column (l&15) of the [4 rows][16 cols] block: value = group*64 + j*16 + (l&15)
+  l = np.arange(64)[:, None]
+  j = np.arange(4)[None, :]
+  want = (l >> 4) * 64 + j * 16 + (l & 15)
+  assert (got == want).all(), f'ds_read_b64_tr_b16 semantics differ:\n{got[:20]}'
+
+
+def test_probe_mfma32_layout(ops):
+  g = torch.Generator().manual_seed(0)
+  A = torch.randn(32, 16, generator=g).bfloat16().float()
+  B = torch.randn(16, 32, generator=g).bfloat16().float()  # asymmetric: catches transposes
+  got = ops.probe_mfma32(A.cuda(), B.cuda())
+  close(got, A @ B, 1e-5, 'mfma 32x32x16 layout')
+
+
+# --------------------------------------------------------------------------------------
+# casts / embedding
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(8, 8), (64, 64), (136, 72), (2304, 768), (50280, 768)])
+def test_cast_transpose(ops, shape):
+  x = torch.randn(shape, device='cuda')
+  y, yt = ops.cast_bf16_t(x)
+  assert torch.equal(y, x.bfloat16())
+  assert torch.equal(yt, x.bfloat16().t().contiguous())
+
+
+@pytest.mark.parametrize('n', [1, 7, 8, 1000, 1 << 20])
+def test_cast_flat(ops, n):
+  x = torch.randn(n, device='cuda')
+  assert torch.equal(ops.cast_bf16(x), x.bfloat16())
+
+
+def test_embedding_fwd_bwd_repeated_ids(ops, golden_dir):
+  z = np.load(f'{golden_dir}/ops.npz')
+  W = torch.from_numpy(z['emb_w']).cuda()
+  ids = torch.from_numpy(z['emb_ids']).cuda().reshape(-1)
+  out = ops.embed_fwd(ids, W)
+  assert torch.equal(out.cpu(), torch.from_numpy(z['emb_out']).reshape(-1, W.shape[1]))
+  dW = torch.zeros_like(W)
+  ops.embed_bwd(ids, torch.from_numpy(z['emb_dout']).cuda().reshape(-1, W.shape[1]).contiguous(), dW)
+  close(dW, torch.from_numpy(z['emb_dw']), 1e-6, 'embedding bwd (golden)')
+
+
+# --------------------------------------------------------------------------------------
+# RMSNorm
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,d', [(48, 128), (1000, 768), (37, 1024), (64, 2048), (5, 64)])
+@pytest.mark.parametrize('with_branch', [False, True])
+def test_rmsnorm_fwd_bwd(ops, M, d, with_branch):
+  g = torch.Generator().manual_seed(M * d)
+  x = torch.randn(M, d, generator=g)
+  w = 1 + 0.1 * torch.randn(d, generator=g)
+  br = bf(0.5 * torch.randn(M, d, generator=g)) if with_branch else None
+  dy = bf(torch.randn(M, d, generator=g))
+  gin = torch.randn(M, d, generator=g)
+  r = (x + br.float()) if with_branch else x
+  rr = r.clone().requires_grad_(True)
+  ww = w.clone().requires_grad_(True)
+  yref = O.rmsnorm(rr, ww)
+  yref.backward(dy.float())
+  xout, y, rstd = ops.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-6, branch=None if br is None else br.cuda(), write_xout=True)
+  close(xout, r, 1e-7, 'xout')
+  close(y.float(), yref, 6e-3, 'rmsnorm y (bf16 out)')
+  close(rstd, torch.rsqrt(r.pow(2).mean(-1) + 1e-6), 1e-5, 'rstd')
+  dx, dxb, dw = ops.rmsnorm_bwd(dy.cuda(), xout, w.cuda(), rstd, gin=gin.cuda(), want_bf16=True)
+  close(dx, rr.grad + gin, 2e-5, 'rmsnorm dx')
+  assert torch.equal(dxb, dx.bfloat16())
+  close(dw, ww.grad, 2e-5, 'rmsnorm dw')
+  # accumulate into an existing dw
+  acc = torch.ones(d, device='cuda')
+  ops.rmsnorm_bwd(dy.cuda(), xout, w.cuda(), rstd, dw_out=acc, dw_accumulate=True)
+  close(acc, ww.grad + 1, 2e-5, 'rmsnorm dw accumulate')
+
+
+def test_rmsnorm_golden(ops, golden_dir):
+  z = {k: torch.from_numpy(v) for k, v in np.load(f'{golden_dir}/ops.npz').items() if k.startswith('rms_')}
+  _, y, rstd = ops.rmsnorm_fwd(z['rms_x'].cuda(), z['rms_w'].cuda(), 1e-6)
+  close(y.float(), z['rms_y'], 6e-3, 'rmsnorm y vs reference')
+  dx, _, dw = ops.rmsnorm_bwd(bf(z['rms_dy']).cuda(), z['rms_x'].cuda(), z['rms_w'].cuda(), rstd)
+  close(dx, z['rms_dx'], 8e-3, 'rmsnorm dx vs reference (dy rounded to bf16)')
+  close(dw, z['rms_dw'], 8e-3, 'rmsnorm dw vs reference')
+
+
+# --------------------------------------------------------------------------------------
+# SwiGLU
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,h', [(48, 512), (333, 2048), (16, 2816)])
+def test_swiglu_fwd_bwd(ops, M, h):
+  g = torch.Generator().manual_seed(h)
+  u = bf(2 * torch.randn(M, 2 * h, generator=g))
+  dout = bf(torch.randn(M, h, generator=g))
+  uu = u.float().requires_grad_(True)
+  ref = O.swiglu(uu, h)
+  ref.backward(dout.float())
+  out = ops.swiglu_fwd(u.cuda())
+  close(out.float(), ref, 1.6e-2, 'swiglu fwd')
+  du = ops.swiglu_bwd(dout.cuda(), u.cuda())
+  close(du.float(), uu.grad, 1.6e-2, 'swiglu bwd')
+  # bit-exact against the reference's bf16 autograd chain evaluated with torch bf16 ops
+  ub = u.cuda().requires_grad_(True)
+  x, z = ub.split(h, dim=1)
+  yb = torch.nn.functional.silu(x) * z
+  yb.backward(dout.cuda())
+  assert (out.float() - yb.float()).abs().max() <= 2 ** -7 * yb.float().abs().max()
+  assert (du.float() - ub.grad.float()).abs().max() <= 2 ** -6 * ub.grad.float().abs().max()
+
+
+# --------------------------------------------------------------------------------------
+# GEMMs
+# --------------------------------------------------------------------------------------
+NT_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1000, 2304, 768), (64, 50280, 768), (512, 768, 50280),
+             (1, 8, 8), (4096, 768, 2048)]
+
+
+@pytest.mark.parametrize('M,N,K', NT_SHAPES)
+def test_gemm_nt(ops, M, N, K):
+  g = torch.Generator().manual_seed(M + N + K)
+  A = bf(torch.randn(M, K, generator=g)).cuda()
+  B = bf(torch.randn(N, K, generator=g)).cuda()
+  ref = A.float() @ B.float().t()
+  out32 = ops.gemm_nt(A, B, out_dtype=torch.float32)
+  close(out32, ref, 2e-5 * math.sqrt(K), f'gemm_nt fp32 {M}x{N}x{K}')
+  out16 = ops.gemm_nt(A, B)
+  close(out16.float(), ref, 6e-3, f'gemm_nt bf16 {M}x{N}x{K}')
+  # accumulate + device alpha
+  alpha = torch.tensor(0.5, device='cuda')
+  acc = torch.ones(M, N, device='cuda')
+  ops.gemm_nt(A, B, out=acc, accumulate=True, alpha=alpha)
+  close(acc, 1 + 0.5 * ref, 2e-5 * math.sqrt(K), 'gemm_nt accumulate/alpha')
+
+
+def test_gemm_nt_strided_operand(ops):
+  """A is a column block of a wider buffer (the q|k|v and x|z cases)."""
+  g = torch.Generator().manual_seed(5)
+  big = bf(torch.randn(300, 3 * 128, generator=g)).cuda()
+  A = big[:, 128:256]
+  B = bf(torch.randn(72, 128, generator=g)).cuda()
+  close(ops.gemm_nt(A, B, out_dtype=torch.float32), A.float() @ B.float().t(), 1e-4, 'gemm_nt strided A')
+
+
+TN_SHAPES = [(128, 128, 64), (256, 128, 512), (136, 72, 200), (2304, 768, 4096), (768, 2048, 1000), (50280, 768, 256),
+             (8, 8, 8), (768, 768, 32768)]
+
+
+@pytest.mark.parametrize('M,N,K', TN_SHAPES)
+def test_gemm_tn(ops, M, N, K):
+  g = torch.Generator().manual_seed(M + 3 * N + K)
+  A = bf(torch.randn(K, M, generator=g)).cuda()
+  B = bf(torch.randn(K, N, generator=g)).cuda()
+  ref = A.float().t() @ B.float()
+  out = ops.gemm_tn(A, B)
+  close(out, ref, 2e-5 * math.sqrt(K), f'gemm_tn {M}x{N}x{K}')
+  acc = torch.full((M, N), 2.0, device='cuda')
+  alpha = torch.tensor(0.25, device='cuda')
+  ops.gemm_tn(A, B, out=acc, accumulate=True, alpha=alpha)
+  close(acc, 2 + 0.25 * ref, 2e-5 * math.sqrt(K), 'gemm_tn accumulate/alpha')
+
+
+def test_gemm_linearity(ops):
+  """Size-independent property at a full-size shape: G(a1+a2) == G(a1)+G(a2) for exactly-representable inputs."""
+  g = torch.Generator().manual_seed(9)
+  M, N, K = 32768, 768, 768
+  A1 = torch.randint(-4, 5, (M, K), generator=g).float()
+  A2 = torch.randint(-4, 5, (M, K), generator=g).float()
+  B = torch.randint(-4, 5, (N, K), generator=g).float()
+  f = lambda a: ops.gemm_nt(bf(a).cuda(), bf(B).cuda(), out_dtype=torch.float32)
+  assert torch.equal(f(A1 + A2), f(A1) + f(A2))  # small integers: every partial sum is exact in fp32
+
+
+# --------------------------------------------------------------------------------------
+# attention (with in-kernel RoPE) vs the oracle
+# --------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, T, nh, doc_start):
+  hd = 64
+  cos, sin = O.rope_table(hd, T)
+  q, k, v = (t.reshape(B, T, nh, hd) for t in qkv.float().split(nh * hd, dim=1))
+  qr = O.rope_apply(q, cos, sin)
+  kr = O.rope_apply(k, cos, sin)
+  return O.attention(qr, kr, v, doc_start).reshape(B * T, nh * hd)
+
+
+def _random_docs(B, T, seed):
+  rng = np.random.default_rng(seed)
+  out = []
+  for _ in range(B):
+    lens, tot = [], 0
+    while tot < T + 1:
+      n = int(min(rng.integers(1, max(2, T // 3)), T + 1 - tot))
+      lens.append(n)
+      tot += n
+    out.append(lens)
+  return out
+
+
+@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (1, 128, 1), (2, 256, 3), (1, 1024, 2), (1, 200, 2), (1, 2048, 1)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_attention_fwd_bwd(ops, B, T, nh, masked):
+  g = torch.Generator().manual_seed(T * nh + masked)
+  d = nh * 64
+  qkv = bf(torch.randn(B * T, 3 * d, generator=g))
+  dout = bf(torch.randn(B * T, d, generator=g))
+  ds = O.doc_start_from_lengths(_random_docs(B, T, T), T) if masked else None
+  leaf = qkv.float().requires_grad_(True)
+  ref = _attn_ref(leaf, B, T, nh, ds)
+  ref.backward(dout.float())
+  cos, sin = (t.cuda() for t in O.rope_table(64, T))
+  dsg = None if ds is None else ds.cuda()
+  out, lse = ops.attn_fwd(qkv.cuda(), cos, sin, B, T, nh, dsg)
+  close(out.float(), ref, 1.6e-2, 'attention out')
+  dqkv = ops.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, cos, sin, B, T, nh, dsg)
+  gq, gk, gv = (t for t in leaf.grad.split(d, dim=1))
+  dq, dk, dv = (t.float() for t in dqkv.split(d, dim=1))
+  close(dv, gv, 2e-2, 'attention dV')
+  close(dk, gk, 2e-2, 'attention dK')
+  close(dq, gq, 2e-2, 'attention dQ')
+
+
+def test_attention_softmax_rescale_branch(ops):
+  """Force a large running-max jump late in the row (guide rule: rare data-dependent branch needs its own test)."""
+  B, T, nh, d = 1, 256, 1, 64
+  g = torch.Generator().manual_seed(3)
+  qkv = 0.3 * torch.randn(B * T, 3 * d, generator=g)
+  qkv[200, d:2 * d] = 6.0   # key 200 spikes
+  qkv[230:, 0:d] += 2.0     # queries after it align with the spike
+  qkv = bf(qkv)
+  ref = _attn_ref(qkv, B, T, nh, None)
+  cos, sin = (t.cuda() for t in O.rope_table(64, T))
+  out, _ = ops.attn_fwd(qkv.cuda(), cos, sin, B, T, nh)
+  close(out.float(), ref, 1.6e-2, 'attention with max jump')
+
+
+def test_attention_golden(ops, golden_dir):
+  """SDPA vectors produced by the reference itself (no RoPE: identity table)."""
+  z = {k: torch.from_numpy(v) for k, v in np.load(f'{golden_dir}/ops.npz').items() if k.startswith('att')}
+  B, T, nh, hd = z['attc_q'].shape
+  cos = torch.ones(T, hd // 2).cuda()
+  sin = torch.zeros(T, hd // 2).cuda()
+  for tag in 'cm':
+    qkv = bf(torch.cat([z[f'att{tag}_{n}'].reshape(B * T, nh * hd) for n in 'qkv'], dim=1)).cuda()
+    ds = None
+    if tag == 'm':
+      docs = [[int(v) for v in row if v > 0] for row in z['attm_docs_lengths']]
+      ds = O.doc_start_from_lengths(docs, T).cuda()
+    out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh, ds)
+    close(out.float(), z[f'att{tag}_o'], 2e-2, f'attention golden {tag}')
+    dqkv = ops.attn_bwd(qkv, out, bf(z[f'att{tag}_do']).cuda(), lse, cos, sin, B, T, nh, ds)
+    for i, n in enumerate('qkv'):
+      close(dqkv[:, i * nh * hd:(i + 1) * nh * hd].float(), z[f'att{tag}_d{n}'].reshape(B * T, nh * hd), 3e-2, f'golden d{n} {tag}')
+
+
+# --------------------------------------------------------------------------------------
+# cross entropy
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,V', [(48, 777), (64, 256), (33, 50280), (8, 8192 * 8), (4, 70000)])
+def test_cross_entropy(ops, M, V):
+  g = torch.Generator().manual_seed(V)
+  logits = bf(3 * torch.randn(M, V, generator=g))
+  tgt = torch.randint(0, V, (M,), generator=g)
+  leaf = logits.float().requires_grad_(True)
+  loss = O.cross_entropy(leaf, tgt)
+  loss.backward()
+  buf = logits.cuda().clone()
+  rows = ops.ce_fwd_bwd_(buf, tgt.cuda(), 1.0 / M)
+  lm = ops.mean(rows)
+  assert abs(lm.item() - loss.item()) <= 2e-6 * abs(loss.item()) + 1e-6
+  close(buf.float(), leaf.grad, 8e-3, 'dlogits (bf16)')
+
+
+def test_cross_entropy_golden(ops, golden_dir):
+  z = np.load(f'{golden_dir}/ops.npz')
+  logits = bf(torch.from_numpy(z['ce_logits'])).cuda()
+  ref = O.cross_entropy(logits.float().cpu(), torch.from_numpy(z['ce_targets']))
+  rows = ops.ce_fwd_bwd_(logits, torch.from_numpy(z['ce_targets']).cuda(), 1.0 / logits.shape[0])
+  assert abs(ops.mean(rows).item() - ref.item()) < 1e-5
+  assert abs(ref.item() - float(z['ce_loss'])) < 2e-2  # bf16 rounding of the logits only
+
+
+# --------------------------------------------------------------------------------------
+# optimizer tail
+# --------------------------------------------------------------------------------------
+def test_sumsq_and_adamw(ops):
+  g = torch.Generator().manual_seed(1)
+  n = 1_000_003
+  x = torch.randn(n + 1, generator=g).cuda()[:n]  # odd length
+  x = x.clone()
+  got = ops.sumsq(x)
+  assert abs(got.item() - (x.double() ** 2).sum().item()) < 1e-4 * n
+  p = torch.randn(4096, generator=g).cuda()
+  gr = torch.randn(4096, generator=g).cuda()
+  ref = torch.nn.Parameter(p.clone())
+  ref.grad = gr.clone() * 0.5
+  opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, eps=1e-8)
+  m, v = torch.zeros_like(p), torch.zeros_like(p)
+  clip = torch.tensor(0.5, device='cuda')
+  for step in (1, 2, 3):
+    opt.step()
+    ops.adamw_(p, gr, m, v, 1e-2, 0.9, 0.95, 1e-8, 0.1, step, clip)
+  close(p, ref.detach(), 1e-5, 'adamw vs torch.optim.AdamW')

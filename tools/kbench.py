@@ -1,0 +1,121 @@
+"""Per-kernel micro-benchmarks at the 160M shapes (B=32, T=1024, d=768, h=2048, V=50280).
+Prints achieved TFLOP/s (MFMA kernels) or GB/s of ALGORITHMIC bytes (HBM kernels).
+Usage: python tools/kbench.py [--iters 20] [--only gemm,attn,...]
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from plainlm_amd import ops  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters, warmup=3):
+  for _ in range(warmup):
+    fn()
+  torch.cuda.synchronize()
+  s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  s.record()
+  for _ in range(iters):
+    fn()
+  e.record()
+  torch.cuda.synchronize()
+  return s.elapsed_time(e) / iters  # ms
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--iters', type=int, default=20)
+  ap.add_argument('--only', default='')
+  ap.add_argument('--B', type=int, default=32)
+  ap.add_argument('--T', type=int, default=1024)
+  ap.add_argument('--json', default='')
+  a = ap.parse_args()
+  only = set(a.only.split(',')) if a.only else None
+  B, T, d, nh, h, V = a.B, a.T, 768, 12, 2048, 50280
+  M = B * T
+  dev = 'cuda'
+  rows = []
+
+  def rec(name, ms, flops=None, bytes_=None):
+    r = {'kernel': name, 'ms': round(ms, 4)}
+    if flops:
+      r['TFLOP/s'] = round(flops / ms / 1e9, 1)
+    if bytes_:
+      r['GB/s'] = round(bytes_ / ms / 1e6, 1)
+    rows.append(r)
+    print(json.dumps(r), flush=True)
+
+  def want(k):
+    return only is None or k in only
+
+  if want('gemm'):
+    for name, (m, n, k) in {
+      'nt qkv fwd': (M, 3 * d, d), 'nt out fwd': (M, d, d), 'nt fc1 fwd': (M, 2 * h, d), 'nt fc2 fwd': (M, d, h),
+      'nt head fwd': (M, V, d), 'nt dX qkv': (M, d, 3 * d), 'nt dX fc1': (M, d, 2 * h), 'nt dX fc2': (M, h, d),
+      'nt dX head': (M, d, V)}.items():
+      A = torch.randn(m, k, device=dev).to(BF)
+      Bm = torch.randn(n, k, device=dev).to(BF)
+      out = torch.empty(m, n, device=dev, dtype=BF)
+      rec(name, timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
+      del A, Bm, out
+    for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
+                             'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}.items():
+      A = torch.randn(k, m, device=dev).to(BF)
+      Bm = torch.randn(k, n, device=dev).to(BF)
+      out = torch.zeros(m, n, device=dev)
+      rec(name, timeit(lambda: ops.gemm_tn(A, Bm, out=out, accumulate=True), a.iters), flops=2.0 * m * n * k)
+      del A, Bm, out
+
+  if want('attn'):
+    from oracle import cpu_ref as O
+    cos, sin = (t.to(dev) for t in O.rope_table(64, T))
+    qkv = torch.randn(M, 3 * d, device=dev).to(BF)
+    dout = torch.randn(M, d, device=dev).to(BF)
+    out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh)
+    fl = 2.0 * 2 * B * nh * T * (T + 1) / 2 * 64  # causal-counted QK^T + PV
+    rec('attn fwd', timeit(lambda: ops.attn_fwd(qkv, cos, sin, B, T, nh), a.iters), flops=fl)
+    rec('attn bwd', timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh), a.iters), flops=2.0 * fl)
+
+  if want('hbm'):
+    x = torch.randn(M, d, device=dev)
+    w = torch.ones(d, device=dev)
+    br = torch.randn(M, d, device=dev).to(BF)
+    rec('rmsnorm fwd', timeit(lambda: ops.rmsnorm_fwd(x, w, 1e-6), a.iters), bytes_=6.0 * M * d)
+    rec('add+rmsnorm fwd', timeit(lambda: ops.rmsnorm_fwd(x, w, 1e-6, branch=br), a.iters), bytes_=12.0 * M * d)
+    _, y, rstd = ops.rmsnorm_fwd(x, w, 1e-6)
+    rec('rmsnorm bwd', timeit(lambda: ops.rmsnorm_bwd(y, x, w, rstd, gin=x, want_bf16=True), a.iters), bytes_=16.0 * M * d)
+    u = torch.randn(M, 2 * h, device=dev).to(BF)
+    g = torch.randn(M, h, device=dev).to(BF)
+    rec('swiglu fwd', timeit(lambda: ops.swiglu_fwd(u), a.iters), bytes_=6.0 * M * h)
+    rec('swiglu bwd', timeit(lambda: ops.swiglu_bwd(g, u), a.iters), bytes_=10.0 * M * h)
+    del u, g
+    logits = torch.randn(M, V, device=dev).to(BF)
+    tg = torch.randint(0, V, (M,), device=dev)
+    rec('ce fwd+bwd', timeit(lambda: ops.ce_fwd_bwd_(logits, tg, 1.0 / M), max(3, a.iters // 4)), bytes_=4.0 * M * V)
+    del logits
+    ids = torch.randint(0, V, (M,), device=dev)
+    W = torch.randn(V, d, device=dev)
+    rec('embed fwd', timeit(lambda: ops.embed_fwd(ids, W), a.iters), bytes_=8.0 * M * d + 8.0 * M)
+    dW = torch.zeros(V, d, device=dev)
+    rec('embed bwd', timeit(lambda: ops.embed_bwd(ids, x, dW), a.iters), bytes_=12.0 * M * d)
+    P = torch.randn(2304, 768, device=dev)
+    rec('cast+transpose qkv', timeit(lambda: ops.cast_bf16_t(P), a.iters), bytes_=8.0 * P.numel())
+    flat = torch.randn(162_183_936, device=dev)
+    rec('sumsq 162M', timeit(lambda: ops.sumsq(flat), a.iters), bytes_=4.0 * flat.numel())
+    m_, v_, g_ = torch.zeros_like(flat), torch.zeros_like(flat), torch.randn_like(flat)
+    rec('adamw 162M', timeit(lambda: ops.adamw_(flat, g_, m_, v_, 1e-3, 0.9, 0.95, 1e-8, 0.1, 1), a.iters), bytes_=28.0 * flat.numel())
+
+  if a.json:
+    with open(a.json, 'w') as f:
+      json.dump(rows, f, indent=1)
+
+
+if __name__ == '__main__':
+  main()
