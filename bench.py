@@ -1,0 +1,238 @@
+"""bench.py — throughput of the plainLM hot path (fwd+bwd of the 160M decoder at seq 1024, bf16)
+on N MI355X GPUs of one node, one process per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one fwd+bwd of one micro-batch of 32 x 1024 synthetic tokens per GPU through the fused
+lm_head+cross-entropy loss, including the per-step fp32->bf16 weight casts (what autocast does
+per forward) and, for N > 1, the bucketed RCCL gradient all-reduce overlapped with backward.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+After the timed region rank 0 also (untimed) measures: the same step with per-launch HIP events
+for the roofline object, a full training step (clip + AdamW) for reference, and — at N = 1 —
+the CPU oracle on the host cores as ``cpu_baseline``.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+CONFIGS = {
+  # BASELINE.json configs[1]/[2]: 12-layer d=768 (160M) seq=1024 bf16, batch 32 per GPU
+  '160m': dict(vocab_size=50280, seq_len=1024, d_model=768, n_layers=12, n_heads=12, micro_batch=32),
+  # configs[3]: tr_420M_x8gpu.yaml
+  '420m': dict(vocab_size=50280, seq_len=2048, d_model=1024, n_layers=24, n_heads=16, micro_batch=8),
+}
+
+
+def flops_per_token(c, hidden):
+  """fwd = L(2d*3d + 2d*d + 2d*2h + 2h*d) + L*2d(T+1) + 2dV ; fwd+bwd = 3x."""
+  d, L, T, V = c['d_model'], c['n_layers'], c['seq_len'], c['vocab_size']
+  fwd = L * (2 * d * 3 * d + 2 * d * d + 2 * d * 2 * hidden + 2 * hidden * d) + L * 2 * d * (T + 1) + 2 * d * V
+  return 3 * fwd
+
+
+def build_model(c, device, seed=100):
+  import plainlm_amd as P
+  keys = dict(model='transformer', vocab_size=c['vocab_size'], seq_len=c['seq_len'], d_model=c['d_model'], expand='8/3',
+              n_layers=c['n_layers'], n_heads=c['n_heads'], mlp_class='glu', tie_embeddings=False)
+  cfg = namedtuple('Config', keys.keys())(**keys)
+  torch.manual_seed(seed)
+  from plainlm_amd.transformer import ModelConfig, Transformer
+  from fractions import Fraction
+  model = Transformer(ModelConfig(vocab_size=cfg.vocab_size, seq_len=cfg.seq_len, dim=cfg.d_model,
+                                  expand=float(Fraction(cfg.expand)), n_layers=cfg.n_layers, n_heads=cfg.n_heads, mlp='glu'))
+  return model.to(device)
+
+
+def cpu_baseline(c, budget_s=25.0):
+  """Oracle (oracle/cpu_ref.py, fp32 eager) fwd+bwd on the host cores: B=1 sequences of seq_len tokens."""
+  from oracle import cpu_ref as O
+  ocfg = O.OracleConfig(vocab_size=c['vocab_size'], seq_len=c['seq_len'], dim=c['d_model'], n_layers=c['n_layers'],
+                        n_heads=c['n_heads'])
+  params = O.init_params(ocfg, seed=0)
+  rng = np.random.default_rng(1234)
+  tok = torch.from_numpy(rng.integers(0, c['vocab_size'], size=(1, c['seq_len'] + 1)))
+  ids, tgt = tok[:, :-1], tok[:, 1:]
+  cores = torch.get_num_threads()
+  O.loss_and_grads(params, ocfg, ids, tgt)  # warm-up
+  times, t_all = [], time.time()
+  while len(times) < 5 and (time.time() - t_all) < budget_s:
+    t0 = time.time()
+    O.loss_and_grads(params, ocfg, ids, tgt)
+    times.append(time.time() - t0)
+  med = float(np.median(times))
+  return {'value': round(c['seq_len'] / med, 1), 'unit': 'tokens/s', 'cores': cores, 'kind': 'port',
+          'sample': f'oracle/cpu_ref.py fp32 eager fwd+bwd, batch 1 x {c["seq_len"]} tokens, median of {len(times)} iterations '
+                    f'after 1 warm-up, torch threads={cores}'}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--config', default='160m', choices=sorted(CONFIGS))
+  ap.add_argument('--micro-batch', type=int, default=0)
+  ap.add_argument('--no-extras', action='store_true', help='skip the untimed roofline / full-step / cpu legs')
+  ap.add_argument('--comm', default=None, choices=[None, 'rccl', 'torch'])
+  ap.add_argument('--bucket-mb', type=float, default=64)
+  a = ap.parse_args()
+
+  rank = int(os.environ.get('RANK', 0))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  if world != a.gpus:
+    raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback for the product path')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend='gloo')  # control plane only (barrier, timing max, RCCL id exchange)
+
+  from plainlm_amd import ddp, ops
+  c = dict(CONFIGS[a.config])
+  if a.micro_batch:
+    c['micro_batch'] = a.micro_batch
+  B, T, V = c['micro_batch'], c['seq_len'], c['vocab_size']
+  model = build_model(c, device)
+  hidden = model.layers[0].mlp.hidden_dim
+  flat = model.enable_main_grad()
+  params = list(model.parameters())
+
+  reducer = None
+  if world > 1:
+    comm = ddp.make_comm(device, a.comm)
+    reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb)
+    reducer.broadcast_params([p.data for p in params])
+    model.sink.on_ready = reducer.param_ready
+
+  # synthetic tokens: rank r takes rows r, r+W, ... (DistributedSampler(shuffle=False) order)
+  n_pool = 4
+  rng = np.random.default_rng(1234)
+  tok = torch.from_numpy(rng.integers(0, V, size=(n_pool * B * world, T + 1)))[rank::world]
+  pool = [(tok[i * B:(i + 1) * B, :T].contiguous().to(device), tok[i * B:(i + 1) * B, 1:].contiguous().to(device))
+          for i in range(n_pool)]
+
+  def fwd_bwd(i):
+    ids, tgt = pool[i % n_pool]
+    model.sink.begin_window()
+    if reducer is not None:
+      reducer.begin(sync=True)
+    model.invalidate_shadows()  # a real step changes the weights: redo the bf16 casts every step like autocast
+    loss = model.loss(ids, tgt)
+    loss.backward()
+    if reducer is not None:
+      reducer.finish()
+    return loss
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+
+  for i in range(a.warmup):
+    fwd_bwd(i)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(a.steps):
+    loss = fwd_bwd(i)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tt = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = tt.item()
+  last_loss = float(loss.item())
+
+  ms_per_step = 1e3 * elapsed / a.steps
+  tokens_per_step = B * T * world
+  value = tokens_per_step / (elapsed / a.steps)
+  fpt = flops_per_token(c, hidden)
+  out = {
+    'metric': f'tokens/sec fwd+bwd ({a.config.upper()}, seq={T}, bf16)', 'value': round(value, 1), 'unit': 'tokens/s',
+    'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+    'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+    'config': {'workload': f'plainLM {a.config} decoder ({c["n_layers"]}L d={c["d_model"]} nh={c["n_heads"]} h={hidden} V={V}) '
+                           f'fwd+bwd incl. per-step weight casts' + (' + bucketed RCCL grad all-reduce' if world > 1 else ''),
+               'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}'},
+    'tokens_per_sec_per_gpu': round(value / world, 1),
+    'mfu_bf16': round(value / world * fpt / (PEAK_BF16_TFLOPS * 1e12), 4),
+    'flops_per_token': fpt, 'loss': round(last_loss, 4),
+  }
+
+  if not a.no_extras:
+    # ---- roofline leg: identical steps with HIP events around every MFMA kernel launch (untimed) ----
+    ops.PROFILE = []
+    n_prof = 3
+    for i in range(n_prof):
+      fwd_bwd(i)
+    torch.cuda.synchronize()
+    fam = {}
+    for name, fl, s, e in ops.PROFILE:
+      acc = fam.setdefault(name, [0.0, 0.0, 0])
+      acc[0] += fl
+      acc[1] += s.elapsed_time(e)
+      acc[2] += 1
+    ops.PROFILE = None
+    fams = {k: {'TFLOP/s': round(v[0] / v[1] / 1e9, 1), 'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof,
+                'avg_launch_ms': round(v[1] / v[2], 4)} for k, v in fam.items()}
+    dom = max(fams, key=lambda k: fams[k]['ms_per_step'])
+    out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': fams[dom]['TFLOP/s'], 'peak': PEAK_BF16_TFLOPS,
+                       'unit': 'TFLOP/s', 'frac': round(fams[dom]['TFLOP/s'] / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                       'families': fams}
+
+    # ---- full training step (clip + AdamW) for reference, same data (untimed leg) ----
+    if rank == 0 or world > 1:
+      opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.1, fused=True)
+
+      def full(i):
+        fwd_bwd(i)
+        model.attach_grads()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+      for i in range(2):
+        full(i)
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      nfull = max(3, a.steps // 4)
+      for i in range(nfull):
+        full(i)
+      torch.cuda.synchronize()
+      full_ms = 1e3 * (time.perf_counter() - t1) / nfull
+      out['full_step'] = {'ms_per_step': round(full_ms, 3), 'tokens_per_sec_per_gpu': round(B * T / full_ms * 1e3, 1),
+                          'note': 'fwd+bwd + clip_grad_norm_ + torch fused AdamW (rank-local clock, untimed leg)'}
+
+    if world == 1:
+      out['cpu_baseline'] = cpu_baseline(c)
+
+  if rank == 0:
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

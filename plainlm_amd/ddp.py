@@ -1,0 +1,190 @@
+"""Bucketed data-parallel gradient all-reduce over a flat fp32 gradient buffer.
+
+Replaces torch DDP's reducer (engine/engine.py:64-65,104-105):
+gradients are produced by our backward kernels directly into one flat buffer, so a bucket
+is a contiguous span.  When the last parameter of a bucket has been written, an event is
+recorded on the compute stream, the communication stream waits for it and runs one
+all-reduce-mean of the span; ``finish()`` joins the streams before clip/optimizer.
+
+Backends:
+  'rccl'  — RCCL called directly through the C ABI (plm_comm_*) on our side HIP stream.
+  'torch' — torch.distributed (nccl == RCCL on ROCm, gloo on CPU for the world_size>1 tests).
+"""
+
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class RcclComm:
+  """Direct RCCL communicator (one per process = one per GPU)."""
+
+  def __init__(self, rank, world_size, device_index, store_group=None):
+    lib = _lib.load()
+    uid = (C.c_uint8 * 128)()
+    if rank == 0:
+      _lib.check(lib.plm_comm_unique_id(C.cast(uid, C.c_void_p)), 'plm_comm_unique_id')
+    if world_size > 1:
+      # ship the 128-byte id over the already-initialised control-plane group (gloo or nccl)
+      obj = [bytes(uid)] if rank == 0 else [None]
+      dist.broadcast_object_list(obj, src=0, group=store_group)
+      uid = (C.c_uint8 * 128).from_buffer_copy(obj[0])
+    handle = C.c_void_p()
+    _lib.check(lib.plm_comm_init(C.byref(handle), C.cast(uid, C.c_void_p), rank, world_size, device_index), 'plm_comm_init')
+    self.handle, self.lib = handle, lib
+    self.rank, self.world_size = rank, world_size
+
+  def allreduce_avg_(self, span, stream):
+    _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),
+                                                   C.c_void_p(stream.cuda_stream)), 'plm_comm_allreduce_avg_f32')
+
+  def broadcast_(self, span, root, stream):
+    _lib.check(self.lib.plm_comm_broadcast_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(), root,
+                                               C.c_void_p(stream.cuda_stream)), 'plm_comm_broadcast_f32')
+
+  def close(self):
+    if self.handle:
+      self.lib.plm_comm_destroy(self.handle)
+      self.handle = None
+
+
+class TorchDistComm:
+  """torch.distributed backend (gloo on CPU for tests; nccl==RCCL on GPU)."""
+
+  def __init__(self, group=None):
+    self.group = group
+    self.rank = dist.get_rank(group)
+    self.world_size = dist.get_world_size(group)
+
+  def allreduce_avg_(self, span, stream=None):
+    if dist.get_backend(self.group) == 'gloo':  # gloo has no AVG
+      dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group)
+      span.div_(self.world_size)
+    else:
+      dist.all_reduce(span, op=dist.ReduceOp.AVG, group=self.group)
+
+  def broadcast_(self, span, root, stream=None):
+    dist.broadcast(span, src=root, group=self.group)
+
+  def close(self):
+    pass
+
+
+def plan_buckets(spans, cap_bytes):
+  """spans: [(offset, numel)] in parameters() order.  Returns buckets as (lo, hi, [param idx])
+  built from the LAST parameter backwards (the order gradients become ready), each at most
+  cap_bytes unless a single parameter is larger (it then forms its own bucket)."""
+  buckets, cur, cur_bytes = [], [], 0
+  for idx in range(len(spans) - 1, -1, -1):
+    nbytes = spans[idx][1] * 4
+    if cur and cur_bytes + nbytes > cap_bytes:
+      buckets.append(cur)
+      cur, cur_bytes = [], 0
+    cur.append(idx)
+    cur_bytes += nbytes
+  if cur:
+    buckets.append(cur)
+  out = []
+  for b in buckets:
+    lo = min(spans[i][0] for i in b)
+    hi = max(spans[i][0] + spans[i][1] for i in b)
+    assert hi - lo == sum(spans[i][1] for i in b), 'bucket must be a contiguous span'
+    out.append((lo, hi, sorted(b)))
+  return out
+
+
+class GradReducer:
+  """Owns the bucket plan and the side stream.  Usage per optimizer step:
+
+      reducer.begin(sync=is_last_micro_step)     # before backward
+      ... backward: sink.on_ready -> reducer.param_ready(p)
+      reducer.finish()                           # after backward, before clip/optimizer
+  """
+
+  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True):
+    self.flat = flat_grad
+    self.comm = comm
+    self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)))
+    self.index_of = {id(p): i for i, p in enumerate(params)}
+    self.bucket_of = {}
+    for b, (_, _, idxs) in enumerate(self.buckets):
+      for i in idxs:
+        self.bucket_of[i] = b
+    self.on_gpu = flat_grad.is_cuda
+    self.overlap = overlap and self.on_gpu
+    self.stream = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
+    self.sync = False
+    self.pending = None
+    self.launched = []
+
+  def begin(self, sync):
+    self.sync = bool(sync) and self.comm.world_size > 1
+    self.pending = [len(idxs) for (_, _, idxs) in self.buckets]
+    self.launched = []
+
+  def _launch(self, b):
+    lo, hi, _ = self.buckets[b]
+    span = self.flat[lo:hi]
+    if self.on_gpu:
+      ev = torch.cuda.Event()
+      ev.record(torch.cuda.current_stream())
+      self.stream.wait_event(ev)
+      with torch.cuda.stream(self.stream):
+        self.comm.allreduce_avg_(span, self.stream)
+    else:
+      self.comm.allreduce_avg_(span, None)
+    self.launched.append(b)
+
+  def param_ready(self, p):
+    if not self.sync:
+      return
+    i = self.index_of.get(id(p))
+    if i is None:
+      return
+    b = self.bucket_of[i]
+    self.pending[b] -= 1
+    if self.pending[b] == 0 and self.overlap:
+      self._launch(b)
+
+  def finish(self):
+    """Reduce whatever was not launched during backward and make the compute stream wait."""
+    if not self.sync:
+      return
+    for b in range(len(self.buckets)):
+      if b not in self.launched:
+        self._launch(b)
+    if self.on_gpu:
+      torch.cuda.current_stream().wait_stream(self.stream)
+    self.sync = False
+
+  def broadcast_params(self, flat_params_or_list):
+    """C1: rank-0 parameters to every rank once at wrap time."""
+    if self.comm.world_size == 1:
+      return
+    tensors = flat_params_or_list if isinstance(flat_params_or_list, (list, tuple)) else [flat_params_or_list]
+    for t in tensors:
+      if self.on_gpu:
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+          self.comm.broadcast_(t.view(-1), 0, self.stream)
+        torch.cuda.current_stream().wait_stream(self.stream)
+      else:
+        self.comm.broadcast_(t.view(-1), 0, None)
+
+
+def make_comm(device, backend=None, group=None):
+  """Pick the data-plane backend.  On GPU the default is direct RCCL through the C ABI."""
+  world = dist.get_world_size(group) if dist.is_initialized() else 1
+  rank = dist.get_rank(group) if dist.is_initialized() else 0
+  backend = backend or os.environ.get('PLM_COMM', 'rccl' if torch.device(device).type == 'cuda' else 'torch')
+  if backend == 'rccl':
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    return RcclComm(rank, world, idx, store_group=group)
+  if not dist.is_initialized():
+    raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")
+  return TorchDistComm(group)

@@ -1,0 +1,222 @@
+"""Training engine with the reference's ``TorchEngine`` interface (engine/engine.py:37-177)
+on top of the gfx950 kernels: ``HipEngine(model, cfg, device, local_rank, ckpt)``,
+``.step(batch) -> 0-d loss``, ``.eval(loader) -> float``, attributes ``.optimizer``,
+``.scheduler``, ``.scaler``, ``.model``.
+
+Differences that stay inside the contract:
+  * forward uses the fused ``model.loss`` (lm_head + cross-entropy) instead of materialising
+    fp32 logits; the returned loss is the same un-divided micro-batch mean;
+  * torch DDP is replaced by ``ddp.GradReducer`` (bucketed RCCL all-reduce on a side stream,
+    skipped on non-final accumulation micro-steps exactly like ``require_backward_grad_sync``);
+  * document masks travel as ``doc_start[B,T]`` (prefix sums of ``docs_lengths``) instead of a
+    [B,T,T] boolean tensor;
+  * ``eval`` implements the evident intent (sum of losses / number of batches across ranks);
+    the reference's version raises AttributeError at engine.py:175.
+"""
+
+import math
+
+import torch
+import torch.distributed as dist
+
+from .construct import get_param_groups
+from . import ddp
+
+
+# ---- LR schedules (optim/lr_schedule.py:29-105), host-side scalar math --------------------
+class _Schedule:
+  def __init__(self, optimizer):
+    self.optimizer = optimizer
+
+  def set_optim_lr(self, lr):
+    for group in self.optimizer.param_groups:
+      group['lr'] = lr
+
+  def state_dict(self):
+    return {k: v for k, v in self.__dict__.items() if k != 'optimizer'}
+
+  def load_state_dict(self, state):
+    self.__dict__.update(state)
+
+  def step(self):
+    self.iter += 1
+    self.set_optim_lr(self.get_lr(self.iter))
+
+
+class WarmupCosine(_Schedule):
+  def __init__(self, optimizer, lr_start, lr_max, lr_end, warmup_steps, T):
+    super().__init__(optimizer)
+    self.lr_start, self.lr_max, self.lr_end = lr_start, lr_max, lr_end
+    self.warmup_steps, self.T, self.iter = warmup_steps, T, 0
+    self.set_optim_lr(lr_start)
+
+  def get_lr(self, t):
+    if t <= self.warmup_steps:
+      return self.lr_start + (self.lr_max - self.lr_start) / self.warmup_steps * t
+    if t <= self.T:
+      prog = (t - self.warmup_steps) / (self.T - self.warmup_steps)
+      return self.lr_end + 0.5 * (self.lr_max - self.lr_end) * (1 + math.cos(math.pi * prog))
+    return self.lr_end
+
+
+class WarmupConstant(_Schedule):
+  def __init__(self, optimizer, lr_start, lr_max, warmup_steps):
+    super().__init__(optimizer)
+    self.lr_start, self.lr_max, self.warmup_steps, self.iter = lr_start, lr_max, warmup_steps, 0
+    self.set_optim_lr(lr_start)
+
+  def get_lr(self, t):
+    if t <= self.warmup_steps:
+      return self.lr_start + (self.lr_max - self.lr_start) / self.warmup_steps * t
+    return self.lr_max
+
+
+def _steps(value, budget):
+  return value if isinstance(value, int) else int(value * budget)
+
+
+def initialize_scheduler(optimizer, cfg):
+  """optim/init_optim.py:73-137 for the schedulers on the shipped configs' path."""
+  name = getattr(cfg, 'scheduler', None)
+  if name is None:
+    return None
+  warmup = _steps(cfg.warmup_steps, cfg.steps_budget) if getattr(cfg, 'warmup_steps', None) is not None else 0
+  lr_end = None
+  if getattr(cfg, 'lr_end', None) is not None or getattr(cfg, 'lr_end_pct', None) is not None:
+    lr_end = cfg.lr_end if cfg.lr_end is not None else cfg.lr_end_pct * cfg.lr
+  if name == 'warmup_cosine':
+    return WarmupCosine(optimizer, cfg.lr_start, cfg.lr, lr_end, warmup, cfg.steps_budget)
+  if name == 'warmup_constant':
+    return WarmupConstant(optimizer, cfg.lr_start, cfg.lr, warmup)
+  raise NotImplementedError(f'Not implemented scheduler: {name}.')
+
+
+def intialize_optimizer(param_groups, cfg):
+  """(sic) optim/init_optim.py:7-21 — AdamW is the only optimizer on the shipped configs' path."""
+  if cfg.optim != 'adamw':
+    raise NotImplementedError(f'Not implemented optim: {cfg.optim}.')
+  return torch.optim.AdamW(param_groups, lr=cfg.lr, betas=[cfg.beta1, cfg.beta2], weight_decay=cfg.weight_decay,
+                           fused=bool(getattr(cfg, 'fused_optim', True)), eps=getattr(cfg, 'eps', 1e-8))
+
+
+def doc_start_from_lengths(docs_lengths, seq_len):
+  """Host prefix sums: for every token the index of its document's first token, int32 [B, T].
+  Equivalent to the mask of data_prep_utils.py:7-23 cropped at engine.py:23 (lengths sum to T+1)."""
+  rows = []
+  for lens in docs_lengths:
+    lens = [int(v) for v in lens]
+    if sum(lens) != seq_len + 1:
+      raise ValueError('Sum of doc_boundaries does not match max_seq_length.')
+    row, start = [], 0
+    for n in lens:
+      row.extend([start] * n)
+      start += n
+    rows.append(row[:seq_len])
+  return torch.tensor(rows, dtype=torch.int32)
+
+
+def _move_to_device(batch, seq_len, device, intra_doc_masking):
+  """engine/engine.py:13-34 with doc_start instead of the [B,T,T] mask."""
+  ids = batch['input_ids']
+  inputs = ids[:, :seq_len].contiguous()
+  targets = ids[:, 1:seq_len + 1].contiguous()
+  doc_start = doc_start_from_lengths(batch['docs_lengths'], seq_len) if intra_doc_masking else None
+  if not inputs.is_cuda:
+    inputs = inputs.pin_memory().to(device, non_blocking=True)
+    targets = targets.pin_memory().to(device, non_blocking=True)
+  if doc_start is not None:
+    doc_start = doc_start.pin_memory().to(device, non_blocking=True)
+  return inputs, targets, doc_start
+
+
+class HipEngine(torch.nn.Module):
+  def __init__(self, model, cfg, device, local_rank=None, ckpt=None, comm_backend=None, bucket_cap_mb=64):
+    super().__init__()
+    self.micro_steps = 0
+    self.accumulated_samples = 0
+    self.seq_len = cfg.seq_len
+    self.accumulation_steps = cfg.grad_accumulation_steps
+    self.grad_clip = cfg.grad_clip
+    self.dtype = cfg.dtype
+    self.intra_doc_masking = getattr(cfg, 'intra_doc_masking', False)
+    self.device = device
+    if self.dtype != 'bfloat16':
+      raise NotImplementedError(f"dtype '{self.dtype}': the gfx950 kernels implement the bfloat16 flow only")
+    if 'cuda' not in str(device):
+      raise RuntimeError('HipEngine needs an MI355X device (got %r); there is no CPU path' % (device,))
+
+    if getattr(cfg, 'resume', False):
+      model.load_state_dict(ckpt['state_dict'])
+      self.micro_steps = ckpt['step'] * cfg.grad_accumulation_steps
+
+    self.model = model.to(device)
+    flat = self.model.enable_main_grad()
+    self.params = list(self.model.parameters())
+
+    self.reducer = None
+    if dist.is_initialized() and dist.get_world_size() > 1:
+      comm = ddp.make_comm(device, comm_backend)
+      self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb)
+      self.reducer.broadcast_params([p.data for p in self.params])  # DDP ctor's _sync_module_states
+      self.model.invalidate_shadows()
+      self.model.sink.on_ready = self.reducer.param_ready
+
+    self.scaler = torch.amp.GradScaler(enabled=False)  # bf16 needs no loss scaling; kept for checkpoint layout
+    param_groups = get_param_groups(model, cfg.weight_decay)
+    self.optimizer = intialize_optimizer(param_groups, cfg)
+    self.scheduler = initialize_scheduler(self.optimizer, cfg)
+    if getattr(cfg, 'resume', False):
+      self.optimizer.load_state_dict(ckpt['optimizer'])
+      self.scheduler.load_state_dict(ckpt['scheduler'])
+      self.scaler.load_state_dict(ckpt['scaler'])
+
+  def step(self, batch):
+    self.model.train()
+    self.micro_steps += 1
+    self.accumulated_samples += 1
+    inputs, targets, doc_start = _move_to_device(batch, self.seq_len, self.device, self.intra_doc_masking)
+
+    last = self.accumulated_samples == self.accumulation_steps
+    if self.accumulated_samples == 1:
+      self.model.sink.begin_window()
+    if self.reducer is not None:
+      self.reducer.begin(sync=last)
+
+    loss = self.model.loss(inputs, targets, doc_start)
+    loss_val = loss.detach()
+    if torch.isnan(loss_val):
+      raise ValueError('Train loss is nan')
+    (loss / self.accumulation_steps).backward()
+    if self.reducer is not None:
+      self.reducer.finish()
+
+    if last:
+      self.accumulated_samples = 0
+      self.model.attach_grads()
+      if self.grad_clip:
+        torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+      self.optimizer.step()
+      self.optimizer.zero_grad(set_to_none=True)
+      if self.scheduler:
+        self.scheduler.step()
+    return loss_val
+
+  @torch.no_grad()
+  def eval(self, dataloader):
+    self.model.eval()
+    total_loss, num_batches = 0.0, 0
+    for batch in dataloader:
+      inputs, targets, doc_start = _move_to_device(batch, self.seq_len, self.device, self.intra_doc_masking)
+      loss = self.model.loss(inputs, targets, doc_start)
+      if torch.isnan(loss):
+        raise ValueError('Validation loss is nan')
+      total_loss += loss.item()
+      num_batches += 1
+    if dist.is_initialized():
+      t = torch.tensor([total_loss, float(num_batches)], device=self.device, dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.SUM)
+      total_loss, num_batches = t[0].item(), t[1].item()
+    return total_loss / num_batches
+
+
+TorchEngine = HipEngine  # the name train.py imports (train.py:44)

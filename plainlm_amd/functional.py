@@ -1,0 +1,211 @@
+"""torch.autograd.Function wrappers over the HIP kernels (forward + hand-written backward).
+
+dtype flow = the reference's bf16-autocast GPU flow: fp32 residual
+stream and parameters, bf16 activations out of every Linear, fp32 loss, fp32 weight
+gradients.  Weight gradients are either returned to autograd (drop-in mode: works
+under the reference's own engine / DDP) or written straight into a flat fp32 gradient
+buffer through a ``GradSink`` (our engine; enables bucketed RCCL all-reduce that
+overlaps the rest of backward).
+"""
+
+import torch
+
+from . import ops
+
+
+class GradSink:
+  """Routes parameter gradients into ``param.main_grad`` views of one flat fp32 buffer.
+
+  The first write to a parameter inside an accumulation window overwrites, later
+  writes add (covers gradient accumulation and tied embeddings alike).  ``on_ready``
+  is invoked after the kernel producing a parameter's gradient has been enqueued."""
+
+  def __init__(self):
+    self.enabled = False
+    self.written = set()
+    self.on_ready = None  # callable(param) or None
+
+  def begin_window(self):
+    self.written.clear()
+
+  def active_for(self, p):
+    return self.enabled and getattr(p, 'main_grad', None) is not None
+
+  def first_write(self, p):
+    first = id(p) not in self.written
+    self.written.add(id(p))
+    return first
+
+  def ready(self, p):
+    if self.on_ready is not None:
+      self.on_ready(p)
+
+
+class LinearFn(torch.autograd.Function):
+  """y = x W^T (nn.Linear, bias-free: transformer.py:36-37,97; components.py:50-51)."""
+
+  @staticmethod
+  def forward(ctx, x, weight, lin):
+    wb, _ = lin.shadow()
+    ctx.save_for_backward(x)
+    ctx.lin = lin
+    return ops.gemm_nt(x, wb)
+
+  @staticmethod
+  def backward(ctx, dy):
+    (x,) = ctx.saved_tensors
+    lin = ctx.lin
+    dy = dy.contiguous()
+    _, wbt = lin.shadow()
+    dx = ops.gemm_nt(dy, wbt) if ctx.needs_input_grad[0] else None
+    dw = None
+    if ctx.needs_input_grad[1]:
+      sink, p = lin.sink, lin.weight
+      if sink is not None and sink.active_for(p):
+        ops.gemm_tn(dy, x, out=p.main_grad, accumulate=not sink.first_write(p))
+        sink.ready(p)
+      else:
+        dw = ops.gemm_tn(dy, x)
+    return dx, dw, None
+
+
+class EmbedFn(torch.autograd.Function):
+  """nn.Embedding (transformer.py:94,110): fp32 row gather; backward = atomic scatter-add."""
+
+  @staticmethod
+  def forward(ctx, ids, weight, emb):
+    ctx.save_for_backward(ids)
+    ctx.emb = emb
+    ctx.wshape = weight.shape
+    return ops.embed_fwd(ids, weight)
+
+  @staticmethod
+  def backward(ctx, g):
+    (ids,) = ctx.saved_tensors
+    emb = ctx.emb
+    g = g.contiguous()
+    sink, p = emb.sink, emb.weight
+    if sink is not None and sink.active_for(p):
+      if sink.first_write(p):
+        p.main_grad.zero_()
+      ops.embed_bwd(ids, g, p.main_grad)
+      sink.ready(p)
+      return None, None, None
+    dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=g.device)
+    ops.embed_bwd(ids, g, dw)
+    return None, dw, None
+
+
+def _norm_dw(norm, dy, x, w, rstd, gin, want_bf16):
+  """Shared backward of the two norm Functions; returns (dx, dx_bf16, dw_for_autograd)."""
+  sink, p = norm.sink, norm.weight
+  if sink is not None and sink.active_for(p):
+    dx, dxb, _ = ops.rmsnorm_bwd(dy, x, w, rstd, gin=gin, want_bf16=want_bf16, dw_out=p.main_grad,
+                                 dw_accumulate=not sink.first_write(p))
+    sink.ready(p)
+    return dx, dxb, None
+  return ops.rmsnorm_bwd(dy, x, w, rstd, gin=gin, want_bf16=want_bf16)
+
+
+class NormFn(torch.autograd.Function):
+  """y = bf16(RMSNorm(x) * w) for an fp32 x that is not modified (first block)."""
+
+  @staticmethod
+  def forward(ctx, x, weight, norm):
+    _, y, rstd = ops.rmsnorm_fwd(x, weight, norm.eps)
+    ctx.save_for_backward(x, weight, rstd)
+    ctx.norm = norm
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w, rstd = ctx.saved_tensors
+    dx, _, dw = _norm_dw(ctx.norm, dy.contiguous(), x, w, rstd, None, False)
+    return dx, dw, None
+
+
+class AddNormFn(torch.autograd.Function):
+  """(x_new, y) = (x + branch, bf16(RMSNorm(x + branch) * w)): the residual add of
+  transformer.py:81-82 fused with the following RMSNorm (components.py:22-28)."""
+
+  @staticmethod
+  def forward(ctx, x, branch, weight, norm):
+    xout, y, rstd = ops.rmsnorm_fwd(x, weight, norm.eps, branch=branch)
+    ctx.save_for_backward(xout, weight, rstd)
+    ctx.norm = norm
+    ctx.set_materialize_grads(False)
+    return xout, y
+
+  @staticmethod
+  def backward(ctx, g_xout, g_y):
+    xout, w, rstd = ctx.saved_tensors
+    if g_y is None:  # y unused: pure residual add
+      gb = g_xout.to(torch.bfloat16) if g_xout is not None else None
+      return g_xout, gb, None, None
+    gin = g_xout.contiguous() if g_xout is not None else None
+    dx, dxb, dw = _norm_dw(ctx.norm, g_y.contiguous(), xout, w, rstd, gin, True)
+    return dx, dxb, dw, None
+
+
+class SwiGLUFn(torch.autograd.Function):
+  """silu(u[:, :h]) * u[:, h:] (components.py:55-56) in the reference's bf16 rounding order."""
+
+  @staticmethod
+  def forward(ctx, u):
+    ctx.save_for_backward(u)
+    return ops.swiglu_fwd(u)
+
+  @staticmethod
+  def backward(ctx, dout):
+    (u,) = ctx.saved_tensors
+    return ops.swiglu_bwd(dout.contiguous(), u)
+
+
+class AttnFn(torch.autograd.Function):
+  """RoPE + causal/doc-masked SDPA on the raw w_qkv output (transformer.py:43-65)."""
+
+  @staticmethod
+  def forward(ctx, qkv, cos, sin, doc_start, B, T, nh):
+    out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh, doc_start)
+    ctx.save_for_backward(qkv, out, lse, cos, sin)
+    ctx.doc_start = doc_start
+    ctx.dims = (B, T, nh)
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    qkv, out, lse, cos, sin = ctx.saved_tensors
+    B, T, nh = ctx.dims
+    dqkv = ops.attn_bwd(qkv, out, dout.contiguous(), lse, cos, sin, B, T, nh, ctx.doc_start)
+    return dqkv, None, None, None, None, None, None
+
+
+class HeadLossFn(torch.autograd.Function):
+  """lm_head + CrossEntropyLoss (transformer.py:114 + engine.py:111) with the logits buffer
+  turned into dlogits in place; returns the mean token loss (fp32 scalar)."""
+
+  @staticmethod
+  def forward(ctx, y, weight, lin, targets):
+    wb, _ = lin.shadow()
+    logits = ops.gemm_nt(y, wb)
+    rows = ops.ce_fwd_bwd_(logits, targets, 1.0 / logits.shape[0])
+    ctx.save_for_backward(y, logits)
+    ctx.lin = lin
+    return ops.mean(rows)
+
+  @staticmethod
+  def backward(ctx, g):
+    y, dlogits = ctx.saved_tensors
+    lin = ctx.lin
+    alpha = g.to(torch.float32).contiguous()
+    _, wbt = lin.shadow()
+    dy = ops.gemm_nt(dlogits, wbt, alpha=alpha) if ctx.needs_input_grad[0] else None
+    dw = None
+    if ctx.needs_input_grad[1]:
+      sink, p = lin.sink, lin.weight
+      if sink is not None and sink.active_for(p):
+        ops.gemm_tn(dlogits, y, out=p.main_grad, accumulate=not sink.first_write(p), alpha=alpha)
+        sink.ready(p)
+      else:
+        dw = ops.gemm_tn(dlogits, y, alpha=alpha)
+    return dy, dw, None, None

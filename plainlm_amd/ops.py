@@ -18,6 +18,31 @@ def _stream():
   return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, every MFMA
+# kernel launch is bracketed by HIP events on the launch stream and (family, flops, start, end) appended.
+PROFILE = None
+
+
+class _Timed:
+  __slots__ = ('family', 'flops', 'start')
+
+  def __init__(self, family, flops):
+    self.family, self.flops, self.start = family, flops, None
+
+  def __enter__(self):
+    if PROFILE is not None:
+      self.start = torch.cuda.Event(enable_timing=True)
+      self.start.record()
+    return self
+
+  def __exit__(self, *exc):
+    if self.start is not None:
+      end = torch.cuda.Event(enable_timing=True)
+      end.record()
+      PROFILE.append((self.family, self.flops, self.start, end))
+    return False
+
+
 def _p(t):
   return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -143,8 +168,9 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None):
   cd = {BF16: 0, F32: 1}[out.dtype]
   if alpha is not None:
     _need(alpha, F32, 'gemm_nt.alpha')
-  _lib.check(_lib.load().plm_gemm_bf16_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
-                                          int(bool(accumulate)), _p(alpha), _stream()), 'plm_gemm_bf16_nt')
+  with _Timed('gemm_nt', 2.0 * M * N * K):
+    _lib.check(_lib.load().plm_gemm_bf16_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
+                                            int(bool(accumulate)), _p(alpha), _stream()), 'plm_gemm_bf16_nt')
   return out
 
 
@@ -179,8 +205,9 @@ def gemm_tn(A, B, out=None, accumulate=False, alpha=None):
   ws = _tn_workspace(nbytes, A.device) if nbytes else None
   if alpha is not None:
     _need(alpha, F32, 'gemm_tn.alpha')
-  _lib.check(lib.plm_gemm_bf16_tn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K,
-                                  int(bool(accumulate)), _p(alpha), _p(ws), nbytes, _stream()), 'plm_gemm_bf16_tn')
+  with _Timed('gemm_tn', 2.0 * M * N * K):
+    _lib.check(lib.plm_gemm_bf16_tn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K,
+                                    int(bool(accumulate)), _p(alpha), _p(ws), nbytes, _stream()), 'plm_gemm_bf16_tn')
   return out
 
 
@@ -196,8 +223,9 @@ def attn_fwd(qkv, rope_cos, rope_sin, B, T, nh, doc_start=None):
     _need(doc_start, torch.int32, 'attn_fwd.doc_start', 2)
   out = torch.empty((B * T, nh * hd), dtype=BF16, device=qkv.device)
   lse = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
-  _lib.check(_lib.load().plm_attn_fwd(_p(qkv), _p(rope_cos), _p(rope_sin), _p(doc_start), _p(out), _p(lse), B, T, nh, hd,
-                                      _stream()), 'plm_attn_fwd')
+  with _Timed('attn_fwd', 4.0 * B * nh * hd * T * (T + 1) / 2):
+    _lib.check(_lib.load().plm_attn_fwd(_p(qkv), _p(rope_cos), _p(rope_sin), _p(doc_start), _p(out), _p(lse), B, T, nh, hd,
+                                        _stream()), 'plm_attn_fwd')
   return out, lse
 
 
@@ -206,8 +234,9 @@ def attn_bwd(qkv, out, dout, lse, rope_cos, rope_sin, B, T, nh, doc_start=None):
   hd = qkv.shape[1] // (3 * nh)
   dqkv = torch.empty_like(qkv)
   delta = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
-  _lib.check(_lib.load().plm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(rope_cos), _p(rope_sin), _p(doc_start),
-                                      _p(dqkv), _p(delta), B, T, nh, hd, _stream()), 'plm_attn_bwd')
+  with _Timed('attn_bwd', 8.0 * B * nh * hd * T * (T + 1) / 2):
+    _lib.check(_lib.load().plm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(rope_cos), _p(rope_sin), _p(doc_start),
+                                        _p(dqkv), _p(delta), B, T, nh, hd, _stream()), 'plm_attn_bwd')
   return dqkv
 
 

@@ -1,0 +1,294 @@
+"""Llama-style decoder with the reference's module API, running on hand-written gfx950 kernels.
+
+Drop-in contract: same constructor config, same parameter names /
+shapes / dtypes / init distributions, ``model(inputs[B,T] int64, attn_mask) -> logits[B,T,V]``
+called positionally, ``count_params``, ``tie_weights``; ``state_dict`` round-trips with
+the reference (models/transformer.py:86-140).  There is no CPU path: calling the model
+with CPU tensors, or without the built HIP library, raises.
+
+Extra (not in the reference): ``model.loss(inputs, targets, attn_mask)`` fuses lm_head
+with cross-entropy; ``attn_mask`` may also be an int32 ``doc_start[B,T]`` tensor, which
+avoids materialising the O(T^2) boolean mask of engine/engine.py:21-23.
+"""
+
+import math
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+from . import ops
+
+
+@dataclass
+class ModelConfig:
+  """Field-for-field the reference's ModelConfig (models/transformer.py:13-23)."""
+  vocab_size: int
+  seq_len: int
+  dim: int
+  expand: float
+  n_layers: int
+  n_heads: int
+  mlp: str = 'mlp'
+  rmsnorm_eps: float = 1e-6
+  tie_embeddings: bool = False
+
+
+def rope_tables(head_dim, seq_len, theta=500000.0):
+  """cos/sin [T, hd/2] fp32, angle[t,i] = t * theta^(-2i/hd) (models/embeddings.py:8-12;
+  theta = 500000 at models/transformer.py:99).  Built on the host like the reference."""
+  expo = torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim
+  ang = torch.outer(torch.arange(seq_len, dtype=torch.float32), 1.0 / (theta ** expo)).float()
+  return torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+
+
+class HipLinear(nn.Module):
+  """Bias-free Linear: fp32 master ``weight[out, in]`` + lazily refreshed bf16 shadows
+  (``[out,in]`` for y = x W^T and ``[in,out]`` for dX), the analogue of autocast's per-forward
+  weight cast (engine/engine.py:75)."""
+
+  def __init__(self, in_features, out_features):
+    super().__init__()
+    self.in_features, self.out_features = in_features, out_features
+    self.weight = nn.Parameter(torch.empty(out_features, in_features))
+    self.sink = None
+    self._shadow = None
+    self._shadow_key = None
+
+  def shadow(self):
+    w = self.weight
+    key = (w.data_ptr(), w._version, w.device)
+    if self._shadow is None or key != self._shadow_key:
+      self._shadow = ops.cast_bf16_t(w.detach())
+      self._shadow_key = key
+    return self._shadow
+
+  def invalidate(self):
+    self._shadow_key = None
+
+  def forward(self, x):
+    lead = x.shape[:-1]
+    y = Fn.LinearFn.apply(x.reshape(-1, self.in_features), self.weight, self)
+    return y.view(*lead, self.out_features)
+
+  def extra_repr(self):
+    return f'in_features={self.in_features}, out_features={self.out_features}, bias=False'
+
+
+class HipEmbedding(nn.Module):
+  def __init__(self, num_embeddings, embedding_dim):
+    super().__init__()
+    self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+    self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+    self.sink = None
+
+  def forward(self, ids):
+    flat = ids.reshape(-1).contiguous()
+    out = Fn.EmbedFn.apply(flat, self.weight, self)
+    return out.view(*ids.shape, self.embedding_dim)
+
+
+class RMSNorm(nn.Module):
+  """models/components.py:16-28.  Standalone ``forward`` returns the bf16 value the next
+  Linear consumes under autocast (bf16(norm(x) * w))."""
+
+  def __init__(self, dim, eps=1e-6):
+    super().__init__()
+    self.eps = eps
+    self.weight = nn.Parameter(torch.ones(dim))
+    self.sink = None
+
+  def forward(self, x):
+    lead = x.shape
+    y = Fn.NormFn.apply(x.reshape(-1, lead[-1]).contiguous(), self.weight, self)
+    return y.view(lead)
+
+
+class GLU(nn.Module):
+  """SwiGLU MLP with fused fc1 [2h, d] (models/components.py:43-56)."""
+
+  def __init__(self, dim, hidden_dim, multiple_of=256):
+    super().__init__()
+    hidden_dim = multiple_of * ((hidden_dim + multiple_of - 1) // multiple_of)
+    self.hidden_dim = hidden_dim
+    self.fc1 = HipLinear(dim, 2 * hidden_dim)
+    self.fc2 = HipLinear(hidden_dim, dim)
+
+  def forward(self, x):
+    lead = x.shape[:-1]
+    u = self.fc1(x.reshape(-1, x.shape[-1]))
+    return self.fc2(Fn.SwiGLUFn.apply(u)).view(*lead, -1)
+
+
+MLP_CLASSES = {'glu': GLU}
+
+
+class Attention(nn.Module):
+  """models/transformer.py:29-67 — fused QKV projection, RoPE + SDPA in one kernel, output projection."""
+
+  def __init__(self, cfg):
+    super().__init__()
+    assert cfg.dim % cfg.n_heads == 0
+    self.n_heads = cfg.n_heads
+    self.head_dim = cfg.dim // cfg.n_heads
+    self.w_qkv = HipLinear(cfg.dim, 3 * cfg.dim)
+    self.w_out = HipLinear(cfg.dim, cfg.dim)
+
+  def forward(self, x2d, rope, doc_start, B, T):
+    qkv = self.w_qkv(x2d)
+    a = Fn.AttnFn.apply(qkv, rope[0], rope[1], doc_start, B, T, self.n_heads)
+    return self.w_out(a)
+
+
+class Block(nn.Module):
+  def __init__(self, layer_id, cfg):
+    super().__init__()
+    if cfg.mlp not in MLP_CLASSES:
+      raise NotImplementedError(f"mlp class '{cfg.mlp}' is outside the accelerated hot path (only 'glu' is built)")
+    self.attn = Attention(cfg)
+    self.attn_norm = RMSNorm(cfg.dim, cfg.rmsnorm_eps)
+    self.mlp = MLP_CLASSES[cfg.mlp](dim=cfg.dim, hidden_dim=int(cfg.expand * cfg.dim))
+    self.mlp_norm = RMSNorm(cfg.dim, cfg.rmsnorm_eps)
+    self.layer_id = layer_id
+
+  def forward(self, x, branch, rope, doc_start, B, T):
+    """x fp32 [M,d] residual stream, branch bf16 [M,d] = previous block's MLP output (or None).
+    Returns (x_mid, mlp_out): the residual add of the MLP output is fused into the NEXT norm."""
+    if branch is None:
+      n1 = Fn.NormFn.apply(x, self.attn_norm.weight, self.attn_norm)
+    else:
+      x, n1 = Fn.AddNormFn.apply(x, branch, self.attn_norm.weight, self.attn_norm)
+    a = self.attn(n1, rope, doc_start, B, T)
+    x, n2 = Fn.AddNormFn.apply(x, a, self.mlp_norm.weight, self.mlp_norm)
+    u = self.mlp.fc1(n2)
+    return x, self.mlp.fc2(Fn.SwiGLUFn.apply(u))
+
+
+class Transformer(nn.Module):
+  def __init__(self, cfg):
+    super().__init__()
+    self.cfg = cfg
+    self.n_layers = cfg.n_layers
+    if cfg.dim % cfg.n_heads != 0:
+      raise ValueError('dim must be divisible by n_heads')
+    self.head_dim = cfg.dim // cfg.n_heads
+    if self.head_dim != 64:
+      raise NotImplementedError(f'head_dim {self.head_dim}: the gfx950 attention kernel is built for head_dim 64')
+
+    self.embed_tokens = HipEmbedding(cfg.vocab_size, cfg.dim)
+    self.layers = nn.ModuleList([Block(idx, cfg) for idx in range(cfg.n_layers)])
+    self.out_norm = RMSNorm(cfg.dim, cfg.rmsnorm_eps)
+    self.lm_head = HipLinear(cfg.dim, cfg.vocab_size)
+
+    # plain attribute like the reference's freqs_cis: not a buffer, not in state_dict
+    self._rope_host = rope_tables(self.head_dim, cfg.seq_len)
+    self._rope_dev = None
+
+    self.sink = Fn.GradSink()
+    self._flat_grad = None
+    self.apply(self._init_weights)
+    self._scale_residual_branches()
+    if cfg.tie_embeddings:
+      self.tie_weights()
+    self._wire_sink()
+
+  # ---- init (models/transformer.py:116-129) ---------------------------------
+  def _init_weights(self, module):
+    if isinstance(module, (HipLinear, HipEmbedding)):
+      torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)
+
+  def _scale_residual_branches(self):
+    for n, p in self.named_parameters():
+      if n.endswith('fc2.weight') or n.endswith('w_out.weight'):
+        torch.nn.init.normal_(p, mean=0.0, std=0.02 / math.sqrt(2 * self.n_layers))
+
+  def tie_weights(self):
+    self.lm_head.weight = self.embed_tokens.weight
+
+  def count_params(self, non_embedding=True):
+    n_params = sum(p.numel() for p in self.parameters())
+    if non_embedding:
+      n_params -= self.embed_tokens.weight.numel()
+      if self.lm_head.weight is not self.embed_tokens.weight:
+        n_params -= self.lm_head.weight.numel()
+    return n_params
+
+  def _wire_sink(self):
+    for m in self.modules():
+      if isinstance(m, (HipLinear, HipEmbedding, RMSNorm)):
+        m.sink = self.sink
+
+  # ---- flat gradient buffer (our engine / DDP path) ----------------------------
+  def enable_main_grad(self):
+    """Allocate one flat fp32 gradient buffer; every parameter gets a ``main_grad`` view into it
+    (in ``parameters()`` order) and the backward kernels write there directly."""
+    params = list(self.parameters())
+    dev = params[0].device
+    total = sum(p.numel() for p in params)
+    self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+    self._grad_spans = []
+    off = 0
+    for p in params:
+      p.main_grad = self._flat_grad[off:off + p.numel()].view(p.shape)
+      self._grad_spans.append((off, p.numel()))
+      off += p.numel()
+    self.sink.enabled = True
+    return self._flat_grad
+
+  def attach_grads(self):
+    """Expose the flat buffer through ``p.grad`` for optimizers / clipping."""
+    for p in self.parameters():
+      p.grad = p.main_grad
+
+  def invalidate_shadows(self):
+    for m in self.modules():
+      if isinstance(m, HipLinear):
+        m.invalidate()
+
+  # ---- forward ---------------------------------------------------------------------
+  def _rope(self, device):
+    if self._rope_dev is None or self._rope_dev[0].device != device:
+      self._rope_dev = tuple(t.to(device) for t in self._rope_host)
+    return self._rope_dev
+
+  @staticmethod
+  def _doc_start(attn_mask, B, T):
+    if attn_mask is None:
+      return None
+    if attn_mask.dim() == 2 and attn_mask.dtype in (torch.int32, torch.int64):
+      return attn_mask.to(torch.int32).contiguous()
+    if attn_mask.dim() == 3 and attn_mask.dtype == torch.bool:
+      # block-diagonal causal mask of data_prep_utils.py:7-23: first allowed key of every query row
+      if attn_mask.shape != (B, T, T):
+        raise ValueError(f'attn_mask must be [B,T,T]={B, T, T}, got {tuple(attn_mask.shape)}')
+      return attn_mask.to(torch.uint8).argmax(dim=-1).to(torch.int32).contiguous()
+    raise TypeError('attn_mask must be None, a bool [B,T,T] mask or an int32 doc_start [B,T]')
+
+  def _trunk(self, x, attn_mask):
+    if x.dim() != 2 or x.dtype != torch.int64:
+      raise TypeError('inputs must be an int64 [B, T] tensor')
+    if not x.is_cuda:
+      raise RuntimeError('plainlm_amd.Transformer runs on MI355X only (inputs are on CPU; there is no CPU fallback)')
+    B, T = x.shape
+    if T > self.cfg.seq_len:
+      raise ValueError(f'sequence length {T} exceeds cfg.seq_len {self.cfg.seq_len}')
+    rope = self._rope(x.device)
+    doc_start = self._doc_start(attn_mask, B, T)
+    h = self.embed_tokens(x).view(B * T, self.cfg.dim)
+    branch = None
+    for layer in self.layers:
+      h, branch = layer(h, branch, rope, doc_start, B, T)
+    _, y = Fn.AddNormFn.apply(h, branch, self.out_norm.weight, self.out_norm)
+    return y, B, T
+
+  def forward(self, x, attn_mask=None):
+    """inputs int64 [B,T], attn_mask -> bf16 logits [B,T,V] (models/transformer.py:108-114)."""
+    y, B, T = self._trunk(x, attn_mask)
+    return self.lm_head(y).view(B, T, self.cfg.vocab_size)
+
+  def loss(self, x, targets, attn_mask=None):
+    """Mean token cross-entropy (fp32 scalar) with lm_head + CE fused (never keeps fp32 logits)."""
+    y, B, T = self._trunk(x, attn_mask)
+    tg = targets.reshape(-1).contiguous()
+    return Fn.HeadLossFn.apply(y, self.lm_head.weight, self.lm_head, tg)

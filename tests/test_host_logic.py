@@ -1,0 +1,156 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+mirror of the reference's module API has the right names/shapes/init/param groups, the product
+path refuses to run without a GPU, schedules and doc_start match the oracle."""
+
+import os
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+
+import plainlm_amd as P
+from plainlm_amd import _lib, ddp, engine
+from oracle import cpu_ref as O
+
+
+def test_library_exports_every_header_symbol():
+  if not os.path.exists(_lib.LIB_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  lib = _lib.load()
+  names = _lib.header_functions()
+  assert len(names) >= 25
+  assert set(names) == set(_lib.SIGNATURES)
+  for n in names:
+    assert hasattr(lib, n), n
+  assert lib.plm_version() >= 100
+
+
+def _cfg(**over):
+  EC = dict(model='transformer', vocab_size=512, seq_len=128, d_model=128, expand='8/3', n_layers=2, n_heads=2,
+            mlp_class='glu', tie_embeddings=False)
+  EC.update(over)
+  return namedtuple('Config', EC.keys())(**EC)
+
+
+def test_construct_model_names_shapes_init():
+  torch.manual_seed(0)
+  model, mcfg = P.construct_model(_cfg())
+  ocfg = O.OracleConfig(vocab_size=512, seq_len=128, dim=128, n_layers=2, n_heads=2)
+  names = [n for n, _ in model.named_parameters()]
+  assert names == O.param_names(ocfg)
+  assert {n: tuple(p.shape) for n, p in model.named_parameters()} == O.param_shapes(ocfg)
+  assert list(model.state_dict()) == names  # no extra buffers (RoPE table is a plain attribute like the reference's)
+  assert mcfg.expand == 8 / 3 and model.layers[0].mlp.hidden_dim == 512
+  for n, p in model.named_parameters():
+    assert p.dtype == torch.float32
+    if 'norm' in n:
+      assert torch.equal(p.detach(), torch.ones_like(p))
+    else:
+      want = 0.02 / np.sqrt(4) if (n.endswith('fc2.weight') or n.endswith('w_out.weight')) else 0.02
+      assert abs(p.std().item() - want) < 0.05 * want, n
+  assert model.count_params(False) == sum(p.numel() for p in model.parameters())
+  assert model.count_params(True) == model.count_params(False) - 2 * 512 * 128
+
+
+def test_golden_init_statistics(golden_dir):
+  z = np.load(os.path.join(golden_dir, 'model.npz'))
+  torch.manual_seed(1)
+  m = P.Transformer(P.ModelConfig(vocab_size=256, seq_len=64, dim=128, expand=8 / 3, n_layers=2, n_heads=2, mlp='glu'))
+  for i, (n, p) in enumerate(m.named_parameters()):
+    ref = float(z['init_std'][i])
+    got = p.std().item() if p.numel() > 1 and 'norm' not in n else 0.0
+    assert abs(got - ref) <= 0.06 * ref + 1e-12, (n, got, ref)
+  m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w:')})  # reference checkpoint layout
+
+
+def test_tied_embeddings_and_param_groups():
+  model, _ = P.construct_model(_cfg(tie_embeddings=True))
+  assert model.lm_head.weight is model.embed_tokens.weight
+  assert model.count_params(True) == model.count_params(False) - 512 * 128
+  model, _ = P.construct_model(_cfg())
+  groups = P.get_param_groups(model, 0.1)
+  assert groups[0]['weight_decay'] == 0.1 and groups[1]['weight_decay'] == 0.0
+  no_decay = {id(p) for p in groups[1]['params']}
+  for n, p in model.named_parameters():
+    assert (id(p) in no_decay) == ('norm' in n), n
+  assert len(groups[0]['params']) == 10 and len(groups[1]['params']) == 5
+
+
+def test_unsupported_configs_fail_loudly():
+  with pytest.raises(NotImplementedError):
+    P.construct_model(_cfg(model='pythia-160m'))
+  with pytest.raises(NotImplementedError):
+    P.construct_model(_cfg(mlp_class='mlp'))
+  with pytest.raises(NotImplementedError):
+    P.construct_model(_cfg(n_heads=4))  # head_dim 32
+  with pytest.raises(ValueError):
+    P.construct_model(_cfg(d_model=100, n_heads=3))
+
+
+def test_no_cpu_fallback():
+  model, _ = P.construct_model(_cfg())
+  ids = torch.zeros(1, 128, dtype=torch.int64)
+  with pytest.raises(RuntimeError, match='MI355X'):
+    model(ids, None)
+  with pytest.raises(RuntimeError):
+    model.loss(ids, ids)
+  from plainlm_amd import ops
+  with pytest.raises(RuntimeError, match='no CPU path'):
+    ops.rmsnorm_fwd(torch.zeros(4, 128), torch.ones(128), 1e-6)
+  ecfg = namedtuple('C', ['seq_len', 'grad_accumulation_steps', 'grad_clip', 'dtype'])(128, 1, 1.0, 'bfloat16')
+  with pytest.raises(RuntimeError, match='no CPU path'):
+    P.TorchEngine(model, ecfg, 'cpu', None, None)
+
+
+def test_doc_start_and_mask_conversion():
+  docs = [[10, 20, 35], [1, 31, 32, 1]]
+  ds = engine.doc_start_from_lengths(docs, 64)
+  assert torch.equal(ds, O.doc_start_from_lengths(docs, 64))
+  got = P.Transformer._doc_start(O.mask_from_doc_start(ds), 2, 64)
+  assert torch.equal(got, ds)
+  assert P.Transformer._doc_start(None, 2, 64) is None
+  with pytest.raises(ValueError):
+    engine.doc_start_from_lengths([[3, 3]], 64)
+  with pytest.raises(TypeError):
+    P.Transformer._doc_start(torch.zeros(2, 64, 64), 2, 64)
+
+
+def test_rope_tables_match_oracle():
+  from plainlm_amd.transformer import rope_tables
+  c, s = rope_tables(64, 2048)
+  oc, os_ = O.rope_table(64, 2048)
+  assert torch.equal(c, oc) and torch.equal(s, os_)
+
+
+def test_lr_schedule_matches_oracle():
+  p = torch.nn.Parameter(torch.zeros(1))
+  opt = torch.optim.SGD([p], lr=1.0)
+  sch = engine.WarmupCosine(opt, 0.0, 3e-3, 1e-5, 2, 8)
+  assert opt.param_groups[0]['lr'] == 0.0
+  for t in range(1, 12):
+    sch.step()
+    assert opt.param_groups[0]['lr'] == O.warmup_cosine_lr(t, 0.0, 3e-3, 1e-5, 2, 8)
+  st = sch.state_dict()
+  assert 'optimizer' not in st and st['iter'] == 11
+  cfg = namedtuple('C', ['scheduler', 'warmup_steps', 'steps_budget', 'lr_end', 'lr_end_pct', 'lr_start', 'lr'])(
+    'warmup_cosine', 0.1, 4800, 1e-5, None, 0.0, 3e-3)
+  s2 = engine.initialize_scheduler(opt, cfg)
+  assert s2.warmup_steps == 480 and s2.T == 4800
+
+
+def test_bucket_plan():
+  spans, off = [], 0
+  for n in [1000, 10, 300, 300, 10, 5000]:
+    spans.append((off, n))
+    off += n
+  b = ddp.plan_buckets(spans, cap_bytes=4 * 700)
+  # last parameter first; oversize parameters alone; every bucket contiguous; full cover, no overlap
+  assert b[0][2] == [5] and b[-1][2] == [0]
+  covered = sorted((lo, hi) for lo, hi, _ in b)
+  assert covered[0][0] == 0 and covered[-1][1] == off
+  for (l0, h0), (l1, h1) in zip(covered, covered[1:]):
+    assert h0 == l1
+  for lo, hi, idxs in b:
+    assert (hi - lo) * 4 <= 4 * 700 or len(idxs) == 1

@@ -290,8 +290,8 @@ def test_attention_golden(ops, golden_dir):
       docs = [[int(v) for v in row if v > 0] for row in z['attm_docs_lengths']]
       ds = O.doc_start_from_lengths(docs, T).cuda()
     out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh, ds)
-    close(out.float(), z[f'att{tag}_o'], 2e-2, f'attention golden {tag}')
-    dqkv = ops.attn_bwd(qkv, out, bf(z[f'att{tag}_do']).cuda(), lse, cos, sin, B, T, nh, ds)
+    close(out.float(), z[f'att{tag}_o'].reshape(B * T, nh * hd), 2e-2, f'attention golden {tag}')
+    dqkv = ops.attn_bwd(qkv, out, bf(z[f'att{tag}_do']).reshape(B * T, nh * hd).cuda(), lse, cos, sin, B, T, nh, ds)
     for i, n in enumerate('qkv'):
       close(dqkv[:, i * nh * hd:(i + 1) * nh * hd].float(), z[f'att{tag}_d{n}'].reshape(B * T, nh * hd), 3e-2, f'golden d{n} {tag}')
 

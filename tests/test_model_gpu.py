@@ -1,0 +1,233 @@
+"""Whole-path parity on MI355X: model fwd/bwd and engine loss sequence vs the reference's own
+golden vectors (tests/golden, fp32 CPU) and vs the CPU oracle at the 160M shape.
+
+Tolerance for the loss is the north-star's: 1e-4 relative (bf16 kernels vs fp32 CPU reference)."""
+
+import os
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O  # noqa: E402
+
+LOSS_RTOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def P():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import plainlm_amd
+  return plainlm_amd
+
+
+@pytest.fixture(scope='module')
+def mdl(golden_dir):
+  z = np.load(os.path.join(golden_dir, 'model.npz'))
+  return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _weights(mdl):
+  return {k[2:]: v for k, v in mdl.items() if k.startswith('w:')}
+
+
+def _small(P, mdl, main_grad=False):
+  m = P.Transformer(P.ModelConfig(vocab_size=256, seq_len=64, dim=128, expand=8 / 3, n_layers=2, n_heads=2, mlp='glu'))
+  m.load_state_dict(_weights(mdl))
+  m = m.cuda()
+  if main_grad:
+    m.enable_main_grad()
+  return m
+
+
+def relmax(a, ref):
+  a, ref = a.double().cpu(), ref.double().cpu()
+  return ((a - ref).abs().max() / ref.abs().max()).item()
+
+
+def test_state_dict_names_match_reference(P, mdl):
+  m = _small(P, mdl)
+  sd = m.state_dict()
+  assert list(sd) == list(_weights(mdl))
+  for k, v in _weights(mdl).items():
+    assert sd[k].dtype == torch.float32 and tuple(sd[k].shape) == tuple(v.shape)
+    assert torch.equal(sd[k].cpu(), v)
+
+
+def test_logits_and_docmask_vs_reference(P, mdl):
+  m = _small(P, mdl)
+  ids = mdl['tokens'][:, :64].cuda()
+  logits = m(ids, None)
+  assert logits.dtype == torch.bfloat16 and tuple(logits.shape) == (2, 64, 256)
+  assert relmax(logits.float(), mdl['logits']) < 2e-2
+  docs = [[int(v) for v in row if v > 0] for row in mdl['docs_lengths']]
+  ds = O.doc_start_from_lengths(docs, 64)
+  lm = m(ids, ds.cuda())
+  assert relmax(lm.float(), mdl['logits_docmask']) < 2e-2
+  # the reference's own calling convention: a bool [B,T,T] mask
+  lm2 = m(ids, O.mask_from_doc_start(ds).cuda())
+  assert torch.equal(lm, lm2)
+  # a single document is exactly causal
+  one = O.doc_start_from_lengths([[65], [65]], 64).cuda()
+  assert torch.equal(m(ids, one), logits)
+
+
+@pytest.mark.parametrize('main_grad', [False, True])
+def test_loss_and_grads_vs_reference(P, mdl, main_grad):
+  m = _small(P, mdl, main_grad)
+  tok = mdl['tokens']
+  loss = m.loss(tok[:, :64].cuda(), tok[:, 1:65].cuda())
+  ref = mdl['loss'].item()
+  assert abs(loss.item() - ref) <= LOSS_RTOL * abs(ref), (loss.item(), ref)
+  loss.backward()
+  if main_grad:
+    m.attach_grads()
+  worst = {}
+  for n, p in m.named_parameters():
+    worst[n] = relmax(p.grad, mdl['g:' + n])
+  bad = {n: e for n, e in worst.items() if e > 4e-2}
+  assert not bad, f'gradient mismatch: {bad}'
+
+
+def test_reference_style_loss_path(P, mdl):
+  """engine/engine.py:109-112 as written: logits -> torch CrossEntropyLoss -> backward."""
+  m = _small(P, mdl)
+  tok = mdl['tokens']
+  logits = m(tok[:, :64].cuda(), None)
+  loss = torch.nn.CrossEntropyLoss()(logits.float().view(-1, 256), tok[:, 1:65].reshape(-1).cuda())
+  ref = mdl['loss'].item()
+  assert abs(loss.item() - ref) <= LOSS_RTOL * abs(ref)
+  loss.backward()
+  for n, p in m.named_parameters():
+    assert relmax(p.grad, mdl['g:' + n]) < 4e-2, n
+
+
+def test_grad_accumulation_and_tied_embeddings(P, mdl):
+  m = _small(P, mdl, main_grad=True)
+  tok = mdl['tokens']
+  ids, tgt = tok[:, :64].cuda(), tok[:, 1:65].cuda()
+  m.sink.begin_window()
+  m.loss(ids, tgt).backward()
+  g1 = m._flat_grad.clone()
+  m.loss(ids, tgt).backward()  # second micro-step of the same window accumulates
+  assert relmax(m._flat_grad, 2 * g1) < 1e-5
+  m.sink.begin_window()
+  m.loss(ids, tgt).backward()  # new window overwrites
+  assert relmax(m._flat_grad, g1) < 1e-5
+  # tied embeddings: one parameter, gradient = head part + embedding part
+  t = P.Transformer(P.ModelConfig(vocab_size=256, seq_len=64, dim=128, expand=8 / 3, n_layers=2, n_heads=2, mlp='glu',
+                                  tie_embeddings=True))
+  w = _weights(mdl)
+  w['lm_head.weight'] = w['embed_tokens.weight']
+  t.load_state_dict(w)
+  t = t.cuda()
+  assert t.lm_head.weight is t.embed_tokens.weight
+  ocfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2, tie_embeddings=True)
+  ow = {k: v for k, v in w.items() if k != 'lm_head.weight'}
+  ol, og = O.loss_and_grads(ow, ocfg, tok[:, :64], tok[:, 1:65])
+  for mg in (False, True):
+    for p in t.parameters():
+      p.grad = None
+    if mg:
+      t.enable_main_grad()
+    loss = t.loss(ids, tgt)
+    loss.backward()
+    if mg:
+      t.attach_grads()
+    assert abs(loss.item() - ol.item()) <= LOSS_RTOL * abs(ol.item())
+    assert relmax(t.embed_tokens.weight.grad, og['embed_tokens.weight']) < 4e-2
+
+
+def _engine_cfg(**over):
+  EC = dict(model='transformer', vocab_size=256, seq_len=64, d_model=128, expand='8/3', n_layers=2, n_heads=2,
+            mlp_class='glu', tie_embeddings=False, torch_compile=False, micro_batch_size=1, grad_accumulation_steps=4,
+            dtype='bfloat16', optim='adamw', fused_optim=True, lr=3e-3, weight_decay=0.1, beta1=0.9, beta2=0.95,
+            grad_clip=1.0, scheduler='warmup_cosine', warmup_steps=2, cooldown_steps=None, lr_start=0.0, lr_end=1e-5,
+            lr_end_pct=None, steps_budget=8, resume=False, seed=100)
+  EC.update(over)
+  return namedtuple('Config', EC.keys())(**EC)
+
+
+def test_engine_loss_sequence_vs_reference(P, mdl, golden_dir):
+  """engine/engine.py:93-141: 16 micro-steps = 4 optimizer steps (accum 4, clip 1.0, AdamW, warmup-cosine)
+  against the losses the reference's own TorchEngine produced on CPU fp32."""
+  en = np.load(os.path.join(golden_dir, 'engine.npz'))
+  cfg = _engine_cfg()
+  model, _ = P.construct_model(cfg)
+  model.load_state_dict(_weights(mdl))
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  tokens = torch.from_numpy(en['tokens'])
+  losses, lrs = [], []
+  for i in range(tokens.shape[0]):
+    losses.append(eng.step({'input_ids': tokens[i]}).item())
+    if (i + 1) % 4 == 0:
+      lrs.append(eng.optimizer.param_groups[0]['lr'])
+  ref = en['losses']
+  rel = np.abs(np.array(losses) - ref) / np.abs(ref)
+  print('engine loss rel err per micro-step:', np.array2string(rel, precision=2))
+  np.testing.assert_allclose(lrs, en['lrs'], rtol=1e-12)
+  assert rel[:8].max() <= LOSS_RTOL, rel  # first two optimizer windows (lr 0 then 1.5e-3)
+  assert rel.max() <= 5e-4, rel           # bf16 trajectories drift apart slowly afterwards
+  final = {n: p.detach().float().cpu() for n, p in eng.model.named_parameters()}
+  assert relmax(final['out_norm.weight'], torch.from_numpy(en['final:out_norm.weight'])) < 2e-3
+  assert relmax(final['layers.1.mlp.fc2.weight'], torch.from_numpy(en['final:layers.1.mlp.fc2.weight'])) < 5e-2
+
+
+def test_engine_docmask_and_errors(P, mdl):
+  cfg = _engine_cfg(intra_doc_masking=True, grad_accumulation_steps=1)
+  model, _ = P.construct_model(cfg)
+  model.load_state_dict(_weights(mdl))
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  tok = mdl['tokens']
+  docs = [[int(v) for v in row if v > 0] for row in mdl['docs_lengths']]
+  loss = eng.step({'input_ids': tok, 'docs_lengths': docs})
+  ocfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2)
+  ref = O.loss_fn(_weights(mdl), ocfg, tok[:, :64], tok[:, 1:65], O.doc_start_from_lengths(docs, 64))
+  assert abs(loss.item() - ref.item()) <= LOSS_RTOL * abs(ref.item())
+  with pytest.raises(ValueError):
+    eng.step({'input_ids': tok, 'docs_lengths': [[10, 10], [65]]})
+  with pytest.raises(RuntimeError):
+    P.TorchEngine(model, cfg, 'cpu', None, None)
+
+
+def test_eval_mean_over_batches(P, mdl):
+  cfg = _engine_cfg()
+  model, _ = P.construct_model(cfg)
+  model.load_state_dict(_weights(mdl))
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  tok = mdl['tokens']
+  val = eng.eval([{'input_ids': tok[:1]}, {'input_ids': tok[1:]}])
+  ocfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2)
+  w = _weights(mdl)
+  ref = np.mean([O.loss_fn(w, ocfg, tok[i:i + 1, :64], tok[i:i + 1, 1:65]).item() for i in range(2)])
+  assert abs(val - ref) <= LOSS_RTOL * abs(ref)
+
+
+def test_160m_loss_and_grad_parity_vs_oracle(P):
+  """BASELINE configs[1] shape (12L, d=768, 12 heads, V=50280, seq 1024) on 2 sequences:
+  bf16 GPU loss vs fp32 CPU oracle within 1e-4 relative; a few gradients compared too."""
+  ocfg = O.OracleConfig(vocab_size=50280, seq_len=1024, dim=768, n_layers=12, n_heads=12)
+  w = O.init_params(ocfg, seed=7)
+  rng = np.random.default_rng(1234)
+  tok = torch.from_numpy(rng.integers(0, 50280, size=(2, 1025)))
+  ids, tgt = tok[:, :1024], tok[:, 1:]
+  m = P.Transformer(P.ModelConfig(vocab_size=50280, seq_len=1024, dim=768, expand=8 / 3, n_layers=12, n_heads=12, mlp='glu'))
+  m.load_state_dict(w)
+  m = m.cuda()
+  m.enable_main_grad()
+  loss = m.loss(ids.cuda(), tgt.cuda())
+  loss.backward()
+  m.attach_grads()
+  torch.set_num_threads(max(1, os.cpu_count() or 1))
+  oloss, og = O.loss_and_grads(w, ocfg, ids, tgt)
+  rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
+  print(f'160M loss gpu {loss.item():.6f} cpu {oloss.item():.6f} rel {rel:.2e}')
+  assert rel <= LOSS_RTOL
+  for n in ('lm_head.weight', 'out_norm.weight', 'layers.11.mlp.fc2.weight', 'layers.0.attn.w_qkv.weight',
+            'layers.5.attn_norm.weight', 'embed_tokens.weight'):
+    g = dict(m.named_parameters())[n].grad
+    assert relmax(g, og[n]) < 6e-2, (n, relmax(g, og[n]))
