@@ -18,8 +18,13 @@
 // 16-byte halves makes ds_read_b128 across rows r and r+8 conflict-free.
 #include "plm_device.h"
 
+#include <type_traits>
+
 #define HD 64
 #define LOG2E 1.4426950408889634f
+
+// raw v_exp_f32: arguments here are <= 0 (or -inf), so no denormal-range fix-up is needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int R>
 __device__ __forceinline__ int tile_off(int row, int d) {
@@ -76,7 +81,7 @@ __device__ __forceinline__ void zero16(f32x16_t& v) {
 // forward
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
                                                        const float* __restrict__ rsin, const int32_t* __restrict__ doc_start,
                                                        uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
   constexpr int KT = 64;  // kv rows per tile
@@ -171,48 +176,58 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s[kb]);
       }
-      const bool need_mask = HAS_DOC || (kv0 + KT - 1 > qw0);
-      float tmax = -INFINITY;
+      // masking is only needed on tiles that touch the diagonal (or always with document masks)
+      auto softmax_pv = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        float tmax = -INFINITY;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (need_mask) {
-            const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
-            const bool ok = (kvg <= qrow) && (!HAS_DOC || kvg >= dsq);
-            if (!ok) s[kb][r] = -INFINITY;
+          for (int r = 0; r < 16; ++r) {
+            if (MASK) {
+              const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+              const bool ok = (kvg <= qrow) && (!HAS_DOC || kvg >= dsq);
+              if (!ok) s[kb][r] = -INFINITY;
+            }
+            tmax = fmaxf(tmax, s[kb][r]);
           }
-          tmax = fmaxf(tmax, s[kb][r]);
         }
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m, tmax);
-      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f((m - m_safe) * c2);
-      const float mc = m_safe * c2;
-      float psum = 0.f;
-      bf16x8_t pf[4];
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2((m - m_safe) * c2);
+        const float mc = m_safe * c2;
+        float psum = 0.f;
+        bf16x8_t pf[4];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(s[kb][r] * c2 - mc);
-          psum += p;
-          pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
+          for (int r = 0; r < 16; ++r) {
+            const float p = fast_exp2(s[kb][r] * c2 - mc);
+            psum += p;
+            pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
+          }
         }
-      }
-      lsum = lsum * alpha + psum;
-      m = m_new;
+        lsum = lsum * alpha + psum;
+        const bool grew = m_new > m;
+        m = m_new;
+        if (__builtin_amdgcn_ballot_w64(grew) != 0ull) {  // wave-uniform: skip the O rescale when no row max moved
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+          for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-          const int rbase = (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi;
-          o[db] = mfma32(frag_cols<KT>(sV, db, rbase, lane), pf[sp], o[db]);
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
-      }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) {
+            const int rbase = (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi;
+            o[db] = mfma32(frag_cols<KT>(sV, db, rbase, lane), pf[sp], o[db]);
+          }
+        }
+      };
+      if (HAS_DOC || (kv0 + KT - 1 > qw0)) softmax_pv(std::true_type{});
+      else softmax_pv(std::false_type{});
     }
     __syncthreads();
     if (jt + 1 < jt_hi) {
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
 // backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows)
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                             const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv,
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const uint16_t* __re
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (QT * 32 + 128) + 3 * QT * 4];
   char* sQ = smem;
   char* sDO = smem + 4 * (QT * 32 + 128);
-  float* sL = reinterpret_cast<float*>(smem + 2 * 4 * (QT * 32 + 128));
+  float* sL = reinterpret_cast<float*>(smem + 2 * 4 * (QT * 32 + 128));  // lse * log2(e)
   float* sD = sL + QT;
   int* sDS = reinterpret_cast<int*>(sD + QT);
 
@@ -284,12 +299,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const uint16_t* __re
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
   const int kv0 = kt * 128;
-  const int kvrow = kv0 + wave * 32 + l31;
+  const int kvw0 = kv0 + wave * 32;
+  const int kvrow = kvw0 + l31;
   const bool kvalid = kvrow < T;
   const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
   const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
   const float* lrow = lse + ((int64_t)b * nh + h) * T;
   const float* drow = delta + ((int64_t)b * nh + h) * T;
+  const int32_t* dsrow = doc_start + (HAS_DOC ? (int64_t)b * T : 0);
   const float scale = 0.125f, c2 = scale * LOG2E;
 
   bf16x8_t kf[4], vf[4];
@@ -313,73 +330,125 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const uint16_t* __re
 #pragma unroll
   for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
 
+  // query-tile range: from the diagonal down; with document masks stop once a tile's first row starts
+  // after this key block (doc_start is non-decreasing)
   const int nqt = (T + QT - 1) / QT;
-  for (int jq = kv0 / QT; jq < nqt; ++jq) {
-    const int qt0 = jq * QT;
-    if (HAS_DOC) {
-      // doc_start is non-decreasing: once the first row of a query tile starts after this key block,
-      // no later query can see these keys
-      if (doc_start[(int64_t)b * T + qt0] > kv0 + 127) break;
-    }
-    // ---- stage Q (rotated) and dO, plus per-row lse / delta / doc_start
+  const int jq_lo = kv0 / QT;
+  int jq_hi = nqt;
+  if (HAS_DOC) {
+    jq_hi = jq_lo;
+    while (jq_hi < nqt && dsrow[jq_hi * QT] <= kv0 + 127) ++jq_hi;
+  }
+
+  bf16x8_t rq[2], rdo[2];
+  float rL = 0.f, rD = 0.f;
+  int rDS = 0;
+  auto g_load = [&](int qt0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = qt0 + srow[i];
-      bf16x8_t rq = zero_bf16x8(), rdo = zero_bf16x8();
+      rq[i] = zero_bf16x8();
+      rdo[i] = zero_bf16x8();
       if (q < T) {
-        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + q * 32 + schunk[i] * 4);
-        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + q * 32 + schunk[i] * 4);
-        rq = rope8(ld_bf16x8(base + (int64_t)q * ld + schunk[i] * 8), cs, sn, 1.f);
-        rdo = ld_bf16x8(dobase + (int64_t)q * dm + schunk[i] * 8);
+        rq[i] = ld_bf16x8(base + (int64_t)q * ld + schunk[i] * 8);
+        rdo[i] = ld_bf16x8(dobase + (int64_t)q * dm + schunk[i] * 8);
       }
-      const int off = tile_off<QT>(srow[i], schunk[i] * 8);
-      *reinterpret_cast<bf16x8_t*>(sQ + off) = rq;
-      *reinterpret_cast<bf16x8_t*>(sDO + off) = rdo;
     }
     if (t < QT) {
       const int q = qt0 + t;
-      sL[t] = (q < T) ? lrow[q] : 0.f;
-      sD[t] = (q < T) ? drow[q] : 0.f;
-      sDS[t] = (HAS_DOC && q < T) ? doc_start[(int64_t)b * T + q] : 0;
+      rL = (q < T) ? lrow[q] * LOG2E : 0.f;
+      rD = (q < T) ? drow[q] : 0.f;
+      rDS = (HAS_DOC && q < T) ? dsrow[q] : 0;
     }
-    __syncthreads();
+  };
+  auto s_store = [&](int qt0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = tile_off<QT>(srow[i], schunk[i] * 8);
+      // the rotation table is tiny and L2-resident: fetched here rather than held across the MFMA phase
+      const int q = min(qt0 + srow[i], T - 1);
+      const f32x4_t rc = *reinterpret_cast<const f32x4_t*>(rcos + q * 32 + schunk[i] * 4);
+      const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(rsin + q * 32 + schunk[i] * 4);
+      *reinterpret_cast<bf16x8_t*>(sQ + off) = rope8(rq[i], rc, rs, 1.f);
+      *reinterpret_cast<bf16x8_t*>(sDO + off) = rdo[i];
+    }
+    if (t < QT) {
+      sL[t] = rL;
+      sD[t] = rD;
+      sDS[t] = rDS;
+    }
+  };
 
-    const bool wave_active = qt0 + QT - 1 >= kv0 + wave * 32;  // some query at or below this wave's first key
+  if (jq_lo < jq_hi) {
+    g_load(jq_lo * QT);
+    s_store(jq_lo * QT);
+  }
+  __syncthreads();
+  for (int jq = jq_lo; jq < jq_hi; ++jq) {
+    const int qt0 = jq * QT;
+    if (jq + 1 < jq_hi) g_load((jq + 1) * QT);
+    const bool wave_active = qt0 + QT - 1 >= kvw0;  // some query at or below this wave's first key
     if (wave_active) {
+      auto body = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        f32x16_t s, dp;
-        zero16(s);
-        zero16(dp);
+        for (int qb = 0; qb < 2; ++qb) {
+          f32x16_t s, dp;
+          zero16(s);
+          zero16(dp);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma32(frag_rows<QT>(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
-          dp = mfma32(frag_rows<QT>(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
-        }
-        bf16x8_t pf[2], dsf[2];
+          for (int ks = 0; ks < 4; ++ks) {
+            s = mfma32(frag_rows<QT>(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
+            dp = mfma32(frag_rows<QT>(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
+          }
+          bf16x8_t pf[2], dsf[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ql = qb * 32 + mfma32_row(r, hi);
-          const int qg = qt0 + ql;
-          bool ok = (kvrow <= qg) && (qg < T);
-          if (HAS_DOC) ok = ok && (kvrow >= sDS[ql]);
-          const float p = ok ? exp2f(s[r] * c2 - sL[ql] * LOG2E) : 0.f;
-          const float dsv = p * (dp[r] - sD[ql]) * scale;
-          pf[r >> 3][r & 7] = f2bf(p);
-          dsf[r >> 3][r & 7] = f2bf(dsv);
-        }
+          for (int g = 0; g < 4; ++g) {
+            // this lane's query rows for registers 4g..4g+3 are consecutive: one 16-byte read per statistic
+            const int ql0 = qb * 32 + 8 * g + 4 * hi;
+            const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0);
+            const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
+            int ds4[4] = {0, 0, 0, 0};
+            if (MASK && HAS_DOC) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int rbase = qb * 32 + s2 * 16 + 4 * hi;
+              for (int e = 0; e < 4; ++e) ds4[e] = sDS[ql0 + e];
+            }
 #pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            dv[db] = mfma32(frag_cols<QT>(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
-            dk[db] = mfma32(frag_cols<QT>(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e;
+              float p = fast_exp2(s[r] * c2 - L4[e]);
+              if (MASK) {
+                const int qg = qt0 + ql0 + e;
+                bool ok = (kvrow <= qg) && (qg < T);
+                if (HAS_DOC) ok = ok && (kvrow >= ds4[e]);
+                p = ok ? p : 0.f;
+              }
+              const float dsv = p * (dp[r] - D4[e]) * scale;
+              pf[r >> 3][r & 7] = f2bf(p);
+              dsf[r >> 3][r & 7] = f2bf(dsv);
+            }
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int rbase = qb * 32 + s2 * 16 + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+              dv[db] = mfma32(frag_cols<QT>(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
+              dk[db] = mfma32(frag_cols<QT>(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
+            }
           }
         }
-      }
+      };
+      // unmasked fast path: every query of the tile is at/after every key of this wave and inside T
+      const bool need_mask = HAS_DOC || (qt0 < kvw0 + 31) || (qt0 + QT > T);
+      if (need_mask) body(std::true_type{});
+      else body(std::false_type{});
     }
     __syncthreads();
+    if (jq + 1 < jq_hi) {
+      s_store((jq + 1) * QT);
+      __syncthreads();
+    }
   }
 
   if (kvalid) {
@@ -413,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const uint16_t* __re
 // backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows)
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                           const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv, int T,
@@ -466,54 +535,84 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   int jt_lo = 0;
   if (HAS_DOC) jt_lo = doc_start[(int64_t)b * T + q0] / KT;
 
-  for (int jt = jt_lo; jt < jt_hi; ++jt) {
-    const int kv0 = jt * KT;
+  bf16x8_t rk[2], rv[2];
+  f32x4_t rc[2], rs[2];
+  auto g_load = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int kv = kv0 + srow[i];
-      bf16x8_t rk = zero_bf16x8(), rv = zero_bf16x8();
+      rk[i] = zero_bf16x8();
+      rv[i] = zero_bf16x8();
+      rc[i] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+      rs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       if (kv < T) {
         const uint16_t* p = base + (int64_t)kv * ld + schunk[i] * 8;
-        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + kv * 32 + schunk[i] * 4);
-        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + kv * 32 + schunk[i] * 4);
-        rk = rope8(ld_bf16x8(p + dm), cs, sn, 1.f);
-        rv = ld_bf16x8(p + 2 * dm);
+        rk[i] = ld_bf16x8(p + dm);
+        rv[i] = ld_bf16x8(p + 2 * dm);
+        rc[i] = *reinterpret_cast<const f32x4_t*>(rcos + kv * 32 + schunk[i] * 4);
+        rs[i] = *reinterpret_cast<const f32x4_t*>(rsin + kv * 32 + schunk[i] * 4);
       }
-      const int off = tile_off<KT>(srow[i], schunk[i] * 8);
-      *reinterpret_cast<bf16x8_t*>(sK + off) = rk;
-      *reinterpret_cast<bf16x8_t*>(sV + off) = rv;
     }
-    __syncthreads();
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = tile_off<KT>(srow[i], schunk[i] * 8);
+      *reinterpret_cast<bf16x8_t*>(sK + off) = rope8(rk[i], rc[i], rs[i], 1.f);
+      *reinterpret_cast<bf16x8_t*>(sV + off) = rv[i];
+    }
+  };
+
+  if (jt_lo < jt_hi) {
+    g_load(jt_lo * KT);
+    s_store();
+  }
+  __syncthreads();
+  for (int jt = jt_lo; jt < jt_hi; ++jt) {
+    const int kv0 = jt * KT;
+    if (jt + 1 < jt_hi) g_load((jt + 1) * KT);
     const bool wave_active = kv0 <= qw0 + 31;
     if (wave_active) {
+      auto body = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16_t s, dp;
-        zero16(s);
-        zero16(dp);
+        for (int kb = 0; kb < 2; ++kb) {
+          f32x16_t s, dp;
+          zero16(s);
+          zero16(dp);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
-          dp = mfma32(frag_rows<KT>(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
+          for (int ks = 0; ks < 4; ++ks) {
+            s = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
+            dp = mfma32(frag_rows<KT>(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
+          }
+          bf16x8_t dsf[2];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float p = fast_exp2(s[r] * c2 - Lq);
+            if (MASK) {
+              const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+              bool ok = (kvg <= qrow);
+              if (HAS_DOC) ok = ok && (kvg >= dsq);
+              p = ok ? p : 0.f;
+            }
+            dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq) * scale);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int rbase = kb * 32 + s2 * 16 + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols<KT>(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
+          }
         }
-        bf16x8_t dsf[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
-          bool ok = (kvg <= qrow);
-          if (HAS_DOC) ok = ok && (kvg >= dsq);
-          const float p = ok ? exp2f(s[r] * c2 - Lq) : 0.f;
-          dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq) * scale);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int rbase = kb * 32 + s2 * 16 + 4 * hi;
-#pragma unroll
-          for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols<KT>(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
-        }
-      }
+      };
+      if (HAS_DOC || (kv0 + KT - 1 > qw0)) body(std::true_type{});
+      else body(std::false_type{});
     }
     __syncthreads();
+    if (jt + 1 < jt_hi) {
+      s_store();
+      __syncthreads();
+    }
   }
 
   if (qvalid) {
