@@ -36,9 +36,9 @@ const char* plm_last_error_string(void);
 /* ---- parameter casts --------------------------------------------------
  * Replaces autocast's per-forward fp32->bf16 weight casts
  * (engine/engine.py:75,108-109).  The `_t` form also writes the transposed
- * copy dst_t[cols, rows] used by the dX GEMMs. */
+ * copy dst_t[cols, ld_t] (ld_t >= rows; columns rows..ld_t are left untouched) used by the dX GEMMs. */
 int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
-int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols, void* stream);
+int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols, int64_t ld_t, void* stream);
 
 /* ---- embedding (models/transformer.py:94,110) --------------------------
  * fwd: out[m,:] = W[ids[m],:]           ids int64[M], W fp32[V,d], out fp32[M,d]
@@ -100,9 +100,10 @@ int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout,
                  uint16_t* dqkv, float* delta, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream);
 
 /* ---- fused cross-entropy forward+backward (engine/engine.py:81,111) -----
- * logits bf16[M,V] are OVERWRITTEN with dlogits = (softmax - onehot) * grad_scale  (grad_scale = g/M).
+ * logits bf16[M, ld] (row stride ld >= V) are OVERWRITTEN with dlogits = (softmax - onehot) * grad_scale
+ * (grad_scale = g/M); pad columns V..ld are set to zero so the buffer can feed a GEMM with K = ld.
  * loss_rows fp32[M] = logsumexp(l) - l[target].  Then plm_mean_f32 reduces to the scalar mean. */
-int plm_ce_fwd_bwd(uint16_t* logits, const int64_t* targets, float* loss_rows, int64_t M, int64_t V,
+int plm_ce_fwd_bwd(uint16_t* logits, const int64_t* targets, float* loss_rows, int64_t M, int64_t V, int64_t ld,
                    float grad_scale, void* stream);
 int plm_mean_f32(const float* x, float* out, int64_t n, void* stream);
 

@@ -26,7 +26,7 @@ SIGNATURES = {
   'plm_version': (_I, []),
   'plm_last_error_string': (C.c_char_p, []),
   'plm_cast_f32_bf16': (_I, [_P, _P, _I64, _P]),
-  'plm_cast_f32_bf16_t': (_I, [_P, _P, _P, _I64, _I64, _P]),
+  'plm_cast_f32_bf16_t': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_embed_fwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_embed_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_rmsnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
@@ -40,7 +40,7 @@ SIGNATURES = {
   'plm_gemm_bf16_tn': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
-  'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _F, _P]),
+  'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P]),
   'plm_mean_f32': (_I, [_P, _P, _I64, _P]),
   'plm_sumsq_f32': (_I, [_P, _I64, _P, _P, _P]),
   'plm_adamw_f32': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
     if (wave_active) {
       auto body = [&](auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
-#pragma unroll
+#pragma unroll 1
         for (int qb = 0; qb < 2; ++qb) {
           f32x16_t s, dp;
           zero16(s);

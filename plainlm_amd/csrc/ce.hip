@@ -42,10 +42,11 @@ __device__ __forceinline__ MaxSum block_maxsum(MaxSum v, MaxSum* sh) {
 // Fast path: V % 8 == 0 and V <= 1024 * 8 * NCH; row resident in registers.
 template <int NCH>
 __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(uint16_t* __restrict__ logits, const int64_t* __restrict__ targets,
-                                                          float* __restrict__ loss_rows, int64_t V, float grad_scale) {
+                                                          float* __restrict__ loss_rows, int64_t V, int64_t ld,
+                                                          float grad_scale) {
   __shared__ MaxSum sh[16];
   const int64_t row = blockIdx.x;
-  uint16_t* lr = logits + row * V;
+  uint16_t* lr = logits + row * ld;
   const int nvec = (int)(V >> 3);
   const int64_t tgt = targets[row];
   const bool tgt_ok = tgt >= 0 && tgt < V;
@@ -86,15 +87,18 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(uint16_t* __restrict__
       st_bf16x8(lr + c * 8, o);
     }
   }
+  // zero the pad columns V..ld (ld - V < 64)
+  for (int64_t c = V + threadIdx.x; c < ld; c += 1024) lr[c] = 0;
 }
 
 // Generic path (any V): three passes over the row with 2-byte accesses.
 __global__ __launch_bounds__(1024) void ce_fwd_bwd_generic_kernel(uint16_t* __restrict__ logits,
                                                                   const int64_t* __restrict__ targets,
-                                                                  float* __restrict__ loss_rows, int64_t V, float grad_scale) {
+                                                                  float* __restrict__ loss_rows, int64_t V, int64_t ld,
+                                                                  float grad_scale) {
   __shared__ MaxSum sh[16];
   const int64_t row = blockIdx.x;
-  bf16_t* lr = reinterpret_cast<bf16_t*>(logits) + row * V;
+  bf16_t* lr = reinterpret_cast<bf16_t*>(logits) + row * ld;
   const int64_t tgt = targets[row];
   const bool tgt_ok = tgt >= 0 && tgt < V;
   const float xt = tgt_ok ? bf2f(lr[tgt]) : 0.f;
@@ -110,24 +114,25 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_generic_kernel(uint16_t* __re
     if (c == tgt) p -= 1.f;
     lr[c] = f2bf(p * gs);
   }
+  for (int64_t c = V + threadIdx.x; c < ld; c += 1024) lr[c] = f2bf(0.f);
 }
 
-extern "C" int plm_ce_fwd_bwd(uint16_t* logits, const int64_t* targets, float* loss_rows, int64_t M, int64_t V, float grad_scale,
-                              void* stream) {
+extern "C" int plm_ce_fwd_bwd(uint16_t* logits, const int64_t* targets, float* loss_rows, int64_t M, int64_t V, int64_t ld,
+                              float grad_scale, void* stream) {
   PLM_REQUIRE(logits && targets && loss_rows, "plm_ce_fwd_bwd: null pointer");
-  PLM_REQUIRE(M > 0 && V > 0, "plm_ce_fwd_bwd: bad shape M=%ld V=%ld", (long)M, (long)V);
+  PLM_REQUIRE(M > 0 && V > 0 && ld >= V && ld - V < 1024, "plm_ce_fwd_bwd: bad shape M=%ld V=%ld ld=%ld", (long)M, (long)V, (long)ld);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)M), block(1024);
-  const bool fast = (V % 8 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) && V <= 1024 * 8 * 8;
+  const bool fast = (V % 8 == 0) && (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) && V <= 1024 * 8 * 8;
   if (!fast) {
-    hipLaunchKernelGGL(ce_fwd_bwd_generic_kernel, grid, block, 0, s, logits, targets, loss_rows, V, grad_scale);
+    hipLaunchKernelGGL(ce_fwd_bwd_generic_kernel, grid, block, 0, s, logits, targets, loss_rows, V, ld, grad_scale);
   } else {
     const int64_t nch = plm_cdiv(V / 8, 1024);
-    if (nch <= 1) hipLaunchKernelGGL(ce_fwd_bwd_kernel<1>, grid, block, 0, s, logits, targets, loss_rows, V, grad_scale);
-    else if (nch <= 2) hipLaunchKernelGGL(ce_fwd_bwd_kernel<2>, grid, block, 0, s, logits, targets, loss_rows, V, grad_scale);
-    else if (nch <= 4) hipLaunchKernelGGL(ce_fwd_bwd_kernel<4>, grid, block, 0, s, logits, targets, loss_rows, V, grad_scale);
-    else if (nch <= 7) hipLaunchKernelGGL(ce_fwd_bwd_kernel<7>, grid, block, 0, s, logits, targets, loss_rows, V, grad_scale);
-    else hipLaunchKernelGGL(ce_fwd_bwd_kernel<8>, grid, block, 0, s, logits, targets, loss_rows, V, grad_scale);
+    if (nch <= 1) hipLaunchKernelGGL(ce_fwd_bwd_kernel<1>, grid, block, 0, s, logits, targets, loss_rows, V, ld, grad_scale);
+    else if (nch <= 2) hipLaunchKernelGGL(ce_fwd_bwd_kernel<2>, grid, block, 0, s, logits, targets, loss_rows, V, ld, grad_scale);
+    else if (nch <= 4) hipLaunchKernelGGL(ce_fwd_bwd_kernel<4>, grid, block, 0, s, logits, targets, loss_rows, V, ld, grad_scale);
+    else if (nch <= 7) hipLaunchKernelGGL(ce_fwd_bwd_kernel<7>, grid, block, 0, s, logits, targets, loss_rows, V, ld, grad_scale);
+    else hipLaunchKernelGGL(ce_fwd_bwd_kernel<8>, grid, block, 0, s, logits, targets, loss_rows, V, ld, grad_scale);
   }
   PLM_CHECK_LAUNCH("plm_ce_fwd_bwd");
   return PLM_OK;

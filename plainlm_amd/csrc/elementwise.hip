@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 
 // 64x64 tile: write dst (same layout) and dst_t (transposed) from one read of src.
 __global__ __launch_bounds__(256) void cast_f32_bf16_t_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
-                                                              uint16_t* __restrict__ dst_t, int64_t rows, int64_t cols) {
+                                                              uint16_t* __restrict__ dst_t, int64_t rows, int64_t cols,
+                                                              int64_t ld_t) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];  // [col][row], 144-byte rows (16B aligned)
   const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   const int t = threadIdx.x;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_t_kernel(const float* __res
     const int64_t gc = c0 + c, gr = r0 + rch;
     if (gc < cols && gr < rows) {
       const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&tile[c][rch]);
-      st_bf16x8(dst_t + gc * rows + gr, v);
+      st_bf16x8(dst_t + gc * ld_t + gr, v);
     }
   }
 }
@@ -65,12 +66,13 @@ extern "C" int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, voi
 }
 
 extern "C" int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols,
-                                   void* stream) {
+                                   int64_t ld_t, void* stream) {
   PLM_REQUIRE(src && dst && dst_t, "plm_cast_f32_bf16_t: null pointer");
   PLM_REQUIRE(rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0, "plm_cast_f32_bf16_t: rows=%ld cols=%ld must be positive multiples of 8",
               (long)rows, (long)cols);
+  PLM_REQUIRE(ld_t >= rows && ld_t % 8 == 0, "plm_cast_f32_bf16_t: ld_t=%ld must be >= rows and a multiple of 8", (long)ld_t);
   dim3 grid((unsigned)plm_cdiv(cols, 64), (unsigned)plm_cdiv(rows, 64));
-  hipLaunchKernelGGL(cast_f32_bf16_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_t, rows, cols);
+  hipLaunchKernelGGL(cast_f32_bf16_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_t, rows, cols, ld_t);
   PLM_CHECK_LAUNCH("plm_cast_f32_bf16_t");
   return PLM_OK;
 }

@@ -17,6 +17,8 @@
 //
 // Workgroup -> tile map: XCD-aware remap (each XCD gets a contiguous id range) and grouped
 // rasterisation (GROUP_M row-panels x all column tiles) so A panels and B tiles are reused from L2.
+#include <stdlib.h>
+
 #include "plm_device.h"
 
 #define GBM 128
@@ -164,6 +166,140 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NT v2: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write),
+// two LDS buffers, ONE barrier per K-step; C leaves through LDS as full 128-byte row segments.
+// The DMA writes lane-linear (wave-uniform base + lane*16 B), so the XOR swizzle of nt_lds_off() is applied
+// to the per-lane SOURCE address: LDS slot s of row r receives global chunk s ^ ((r>>1)&7).
+// Needs K % 64 == 0 (no K tail), N % 8 == 0 and 16-byte aligned C rows; other shapes use gemm_nt_kernel.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+#define EPI_STRIDE_BF16 144   // 64 bf16 + 16 B pad: 16-byte aligned rows, 2-way at worst on the 8-byte writes
+#define EPI_STRIDE_F32 272    // 64 fp32 + 16 B pad
+
+template <bool OUT_F32, bool ACCUM>
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                          const uint16_t* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
+                                                          int64_t ldc, int M, int N, int K, const float* __restrict__ alpha_dev,
+                                                          int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * GBM * GBK * 2];  // [buf][A|B][16 KiB]
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // DMA assignment: instruction i of wave w fills LDS rows (i*4+w)*8 .. +7 (1 KiB); lane -> (row, slot)
+  const uint16_t* a_src[4];
+  const uint16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int ar = min(m0 + row, M - 1), br = min(n0 + row, N - 1);  // tail rows: any valid address, results unused
+    a_src[i] = A + (int64_t)ar * lda + chunk * 8;
+    b_src[i] = B + (int64_t)br * ldb + chunk * 8;
+  }
+  auto dma_tile = [&](int buf, int k0) {
+    char* dA = smem + buf * (2 * GBM * GBK * 2);
+    char* dB = dA + GBM * GBK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(a_src[i] + k0, dA + (i * 4 + wave) * 1024);
+      dma16(b_src[i] + k0, dB + (i * 4 + wave) * 1024);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / GBK;
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) dma_tile(cur ^ 1, (kt + 1) * GBK);
+    const char* sA = smem + cur * (2 * GBM * GBK * 2);
+    const char* sB = sA + GBM * GBK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sA + nt_lds_off(wm * 64 + i * 32 + l31, ks * 2 + hi));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sB + nt_lds_off(wn * 64 + i * 32 + l31, ks * 2 + hi));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bfr[j], af[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
+    __syncthreads();                                   // ... and everyone's; also: all reads of buf[cur] are done
+  }
+
+  // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row-contiguous global stores ----
+  const float alpha = alpha_dev ? *alpha_dev : 1.f;
+  constexpr int STRIDE = OUT_F32 ? EPI_STRIDE_F32 : EPI_STRIDE_BF16;
+  char* epi = smem + wave * (32 * STRIDE);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // 32 rows (m) x 64 cols (n) of this wave: lane owns row l31, 4-column runs
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = j * 32 + 8 * g + 4 * hi;
+        f32x4_t v = {acc[i][j][4 * g + 0] * alpha, acc[i][j][4 * g + 1] * alpha, acc[i][j][4 * g + 2] * alpha,
+                     acc[i][j][4 * g + 3] * alpha};
+        if (OUT_F32) {
+          *reinterpret_cast<f32x4_t*>(epi + l31 * STRIDE + col * 4) = v;
+        } else {
+          bf16x4_t o;
+          o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+          *reinterpret_cast<bf16x4_t*>(epi + l31 * STRIDE + col * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = OUT_F32 ? 16 : 8;            // 16-byte chunks per 64-column row
+    constexpr int ITERS = 32 * CPR / 64;             // per-lane chunks for 32 rows
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int c = it * 64 + lane;
+      const int row = c / CPR, cc = c % CPR;
+      const int gm = m0 + wm * 64 + i * 32 + row;
+      const int gn = n0 + wn * 64 + cc * (OUT_F32 ? 4 : 8);
+      if (gm < M && gn < N) {
+        if (OUT_F32) {
+          f32x4_t v = *reinterpret_cast<const f32x4_t*>(epi + row * STRIDE + cc * 16);
+          float* dst = reinterpret_cast<float*>(Cv) + (int64_t)gm * ldc + gn;
+          if (ACCUM) v += *reinterpret_cast<const f32x4_t*>(dst);
+          *reinterpret_cast<f32x4_t*>(dst) = v;
+        } else {
+          const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * STRIDE + cc * 16);
+          st_bf16x8(reinterpret_cast<uint16_t*>(Cv) + (int64_t)gm * ldc + gn, v);
+        }
+      }
+    }
+    if (i == 0) __syncthreads();
+  }
+}
+
 extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                                 int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream) {
   PLM_REQUIRE(A && B && C, "plm_gemm_bf16_nt: null pointer");
@@ -178,12 +314,20 @@ extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* 
   const int tiles_m = (int)plm_cdiv(M, GBM), tiles_n = (int)plm_cdiv(N, GBN);
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (c_dtype == 0)
-    hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n);
-  else if (accumulate)
-    hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n);
+  static const bool force_v1 = getenv("PLM_GEMM_V1") != nullptr;
+  const bool dma_ok = !force_v1 && (K % GBK == 0) && (N % 8 == 0) && (ldc % 8 == 0);
+#define PLM_NT_LAUNCH(KERN)                                                                                              \
+  hipLaunchKernelGGL(KERN, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n)
+  if (dma_ok) {
+    if (c_dtype == 0) PLM_NT_LAUNCH((gemm_nt_dma_kernel<false, false>));
+    else if (accumulate) PLM_NT_LAUNCH((gemm_nt_dma_kernel<true, true>));
+    else PLM_NT_LAUNCH((gemm_nt_dma_kernel<true, false>));
+  } else {
+    if (c_dtype == 0) PLM_NT_LAUNCH((gemm_nt_kernel<false, false>));
+    else if (accumulate) PLM_NT_LAUNCH((gemm_nt_kernel<true, true>));
+    else PLM_NT_LAUNCH((gemm_nt_kernel<true, false>));
+  }
+#undef PLM_NT_LAUNCH
   PLM_CHECK_LAUNCH("plm_gemm_bf16_nt");
   return PLM_OK;
 }
@@ -308,6 +452,111 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TN v2: LDS-DMA + two LDS buffers + one barrier per K-step (needs K and the split chunk % 64 == 0).
+// LDS image per operand: [64 k-rows][128 cols] bf16, 256-byte rows, written lane-linear by the DMA
+// (one wave-instruction = 4 full rows: perfectly coalesced source reads).  The 32-byte column pairs of
+// row k are ROTATED by 2*(k&3) pair positions (on the source address): the four rows of a transpose-read
+// block then sit on four different 32-byte bank segments and the two 16-lane groups of a half-wave use
+// the even/odd segments: ds_read_b64_tr_b16 is conflict-free.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                          const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                          int64_t ldc, int M, int N, int K, int kchunk,
+                                                          const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * GBK * GBM * 2];  // [buf][A|B][16 KiB]
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int i0 = tm * GBM, j0 = tn * GBN;
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
+
+  const uint16_t* a_src[4];
+  const uint16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 4 + (lane >> 4);      // k-row inside the tile
+    const int pp = (lane & 15) >> 1, half = lane & 1;       // physical 32-byte pair / 16-byte half
+    const int cb = (pp - 2 * (row & 3)) & 7;                // logical pair stored there
+    const int col = cb * 16 + half * 8;
+    a_src[i] = A + (int64_t)row * lda + min(i0 + col, M - 8);  // column tails: any valid address, results unused
+    b_src[i] = B + (int64_t)row * ldb + min(j0 + col, N - 8);
+  }
+  auto dma_tile = [&](int buf, int k0) {
+    char* dA = smem + buf * (2 * GBK * GBM * 2);
+    char* dB = dA + GBK * GBM * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(a_src[i] + (int64_t)k0 * lda, dA + (i * 4 + wave) * 1024);
+      dma16(b_src[i] + (int64_t)k0 * ldb, dB + (i * 4 + wave) * 1024);
+    }
+  };
+  auto tr_frag = [&](const char* base, int cb0, int ks) -> bf16x8_t {
+    const int row = ks * 16 + hi * 8 + (t16 >> 2);
+    const char* p = base + row * 256 + (((cb0 + ib) + 2 * (row & 3)) & 7) * 32 + (t16 & 3) * 8;
+    return join_tr(lds_read_tr16(p), lds_read_tr16(p + 4 * 256));
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg) / GBK;
+  if (nk > 0) dma_tile(0, kbeg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) dma_tile(cur ^ 1, kbeg + (kt + 1) * GBK);
+    const char* sA = smem + cur * (2 * GBK * GBM * 2);
+    const char* sB = sA + GBK * GBM * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = tr_frag(sA, (wm * 64 + i * 32) >> 4, ks);
+        bfr[i] = tr_frag(sB, (wn * 64 + i * 32) >> 4, ks);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const float alpha = (MODE != 2 && alpha_dev) ? *alpha_dev : 1.f;
+  float* out = (MODE == 2) ? C + (int64_t)blockIdx.y * M * N : C;
+  const int64_t ld = (MODE == 2) ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + mfma32_row(r, hi);
+        if (row >= M) continue;
+        float* dst = out + (int64_t)row * ld + col;
+        const float v = acc[i][j][r] * alpha;
+        *dst = (MODE == 1) ? *dst + v : v;
+      }
+    }
+  }
+}
+
 // C (+)= alpha * sum_s slab[s]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc, int M,
                                                             int N, int splits, int accumulate,
@@ -359,9 +608,16 @@ extern "C" int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* 
   const int splits = tn_splits(M, N, K);
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(256);
+  static const bool force_v1 = getenv("PLM_GEMM_V1") != nullptr;
+  const bool dma_ok = !force_v1 && (K % GBK == 0);
   if (splits == 1) {
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1);
-    if (accumulate)
+    if (dma_ok) {
+      if (accumulate)
+        hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K, alpha_dev, tiles_m, tiles_n);
+      else
+        hipLaunchKernelGGL(gemm_tn_dma_kernel<0>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K, alpha_dev, tiles_m, tiles_n);
+    } else if (accumulate)
       hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K, alpha_dev, tiles_m, tiles_n);
     else
       hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K, alpha_dev, tiles_m, tiles_n);
@@ -376,8 +632,12 @@ extern "C" int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* 
   PLM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "plm_gemm_bf16_tn: workspace must be 16-byte aligned");
   const int kchunk = (int)(plm_cdiv(plm_cdiv(K, splits), GBK) * GBK);
   const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
-  hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, block, 0, s, A, lda, B, ldb, (float*)workspace, (int64_t)N, (int)M, (int)N, (int)K, kchunk,
-                     (const float*)nullptr, tiles_m, tiles_n);
+  if (dma_ok)
+    hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid, block, 0, s, A, lda, B, ldb, (float*)workspace, (int64_t)N, (int)M, (int)N, (int)K, kchunk,
+                       (const float*)nullptr, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, block, 0, s, A, lda, B, ldb, (float*)workspace, (int64_t)N, (int)M, (int)N, (int)K, kchunk,
+                       (const float*)nullptr, tiles_m, tiles_n);
   const int64_t nv = M * (N / 4);
   int64_t rb = plm_cdiv(nv, 256);
   if (rb > 4096) rb = 4096;

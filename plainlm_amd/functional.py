@@ -57,7 +57,7 @@ class LinearFn(torch.autograd.Function):
     lin = ctx.lin
     dy = dy.contiguous()
     _, wbt = lin.shadow()
-    dx = ops.gemm_nt(dy, wbt) if ctx.needs_input_grad[0] else None
+    dx = ops.gemm_nt(dy, wbt[:, :lin.out_features]) if ctx.needs_input_grad[0] else None
     dw = None
     if ctx.needs_input_grad[1]:
       sink, p = lin.sink, lin.weight
@@ -187,19 +187,23 @@ class HeadLossFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, y, weight, lin, targets):
     wb, _ = lin.shadow()
-    logits = ops.gemm_nt(y, wb)
-    rows = ops.ce_fwd_bwd_(logits, targets, 1.0 / logits.shape[0])
-    ctx.save_for_backward(y, logits)
+    M, V = y.shape[0], lin.out_features
+    # rows padded to a multiple of 64 columns: 128-byte aligned rows, and dlogits feeds the dX GEMM with K % 64 == 0
+    buf = torch.empty((M, lin.out_pad), dtype=torch.bfloat16, device=y.device)
+    ops.gemm_nt(y, wb, out=buf[:, :V])
+    rows = ops.ce_fwd_bwd_(buf, targets, 1.0 / M, V=V)
+    ctx.save_for_backward(y, buf)
     ctx.lin = lin
     return ops.mean(rows)
 
   @staticmethod
   def backward(ctx, g):
-    y, dlogits = ctx.saved_tensors
+    y, dbuf = ctx.saved_tensors
     lin = ctx.lin
     alpha = g.to(torch.float32).contiguous()
     _, wbt = lin.shadow()
-    dy = ops.gemm_nt(dlogits, wbt, alpha=alpha) if ctx.needs_input_grad[0] else None
+    dlogits = dbuf[:, :lin.out_features]
+    dy = ops.gemm_nt(dbuf, wbt, alpha=alpha) if ctx.needs_input_grad[0] else None  # K = out_pad, pads are zero on both sides
     dw = None
     if ctx.needs_input_grad[1]:
       sink, p = lin.sink, lin.weight

@@ -68,12 +68,16 @@ def cast_bf16(src, out=None):
 
 
 def cast_bf16_t(src, out=None, out_t=None):
-  """src fp32 [R, C] -> (bf16 [R, C], bf16 [C, R])."""
+  """src fp32 [R, C] -> (bf16 [R, C], bf16 [C, R]).  ``out_t`` may be a zero-initialised [C, R_pad] buffer
+  (R_pad >= R): only its first R columns are written, the pad stays zero (K-padding for the dX GEMM)."""
   _need(src, F32, 'cast_bf16_t.src', 2)
   R, Cc = src.shape
   out = torch.empty((R, Cc), dtype=BF16, device=src.device) if out is None else out
   out_t = torch.empty((Cc, R), dtype=BF16, device=src.device) if out_t is None else out_t
-  _lib.check(_lib.load().plm_cast_f32_bf16_t(_p(src), _p(out), _p(out_t), R, Cc, _stream()), 'plm_cast_f32_bf16_t')
+  if out_t.dtype != BF16 or out_t.dim() != 2 or out_t.shape[0] != Cc or out_t.shape[1] < R or out_t.stride(1) != 1:
+    raise ValueError('cast_bf16_t.out_t: need bf16 [C, >=R]')
+  _lib.check(_lib.load().plm_cast_f32_bf16_t(_p(src), _p(out), _p(out_t), R, Cc, out_t.stride(0), _stream()),
+             'plm_cast_f32_bf16_t')
   return out, out_t
 
 
@@ -241,13 +245,16 @@ def attn_bwd(qkv, out, dout, lse, rope_cos, rope_sin, B, T, nh, doc_start=None):
 
 
 # ---- cross entropy --------------------------------------------------------------------
-def ce_fwd_bwd_(logits, targets, grad_scale):
-  """In place: logits <- (softmax - onehot) * grad_scale. Returns per-row losses fp32[M]."""
+def ce_fwd_bwd_(logits, targets, grad_scale, V=None):
+  """In place: logits[:, :V] <- (softmax - onehot) * grad_scale, logits[:, V:] <- 0 (logits is bf16 [M, ld], ld >= V).
+  Returns per-row losses fp32[M]."""
   _need(logits, BF16, 'ce.logits', 2)
   _need(targets, torch.int64, 'ce.targets', 1)
-  M, V = logits.shape
+  M, ld = logits.shape
+  V = ld if V is None else V
   rows = torch.empty((M,), dtype=F32, device=logits.device)
-  _lib.check(_lib.load().plm_ce_fwd_bwd(_p(logits), _p(targets), _p(rows), M, V, float(grad_scale), _stream()), 'plm_ce_fwd_bwd')
+  _lib.check(_lib.load().plm_ce_fwd_bwd(_p(logits), _p(targets), _p(rows), M, V, ld, float(grad_scale), _stream()),
+             'plm_ce_fwd_bwd')
   return rows
 
 

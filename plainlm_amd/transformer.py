@@ -48,19 +48,25 @@ class HipLinear(nn.Module):
   (``[out,in]`` for y = x W^T and ``[in,out]`` for dX), the analogue of autocast's per-forward
   weight cast (engine/engine.py:75)."""
 
-  def __init__(self, in_features, out_features):
+  def __init__(self, in_features, out_features, pad_out_to=8):
     super().__init__()
     self.in_features, self.out_features = in_features, out_features
+    # the transposed shadow [in, out_pad] is zero-padded along `out` so dX GEMMs see a K that is a multiple of 64
+    self.out_pad = -(-out_features // pad_out_to) * pad_out_to
     self.weight = nn.Parameter(torch.empty(out_features, in_features))
     self.sink = None
     self._shadow = None
     self._shadow_key = None
 
   def shadow(self):
+    """(bf16 W [out, in], bf16 W^T [in, out_pad] with zero pad columns), re-cast when the master weight changed."""
     w = self.weight
     key = (w.data_ptr(), w._version, w.device)
     if self._shadow is None or key != self._shadow_key:
-      self._shadow = ops.cast_bf16_t(w.detach())
+      if self._shadow is None or self._shadow[0].device != w.device:
+        self._shadow = (torch.empty((self.out_features, self.in_features), dtype=torch.bfloat16, device=w.device),
+                        torch.zeros((self.in_features, self.out_pad), dtype=torch.bfloat16, device=w.device))
+      ops.cast_bf16_t(w.detach(), out=self._shadow[0], out_t=self._shadow[1])
       self._shadow_key = key
     return self._shadow
 
@@ -179,7 +185,7 @@ class Transformer(nn.Module):
     self.embed_tokens = HipEmbedding(cfg.vocab_size, cfg.dim)
     self.layers = nn.ModuleList([Block(idx, cfg) for idx in range(cfg.n_layers)])
     self.out_norm = RMSNorm(cfg.dim, cfg.rmsnorm_eps)
-    self.lm_head = HipLinear(cfg.dim, cfg.vocab_size)
+    self.lm_head = HipLinear(cfg.dim, cfg.vocab_size, pad_out_to=64)
 
     # plain attribute like the reference's freqs_cis: not a buffer, not in state_dict
     self._rope_host = rope_tables(self.head_dim, cfg.seq_len)

@@ -157,7 +157,7 @@ def test_swiglu_fwd_bwd(ops, M, h):
 # GEMMs
 # --------------------------------------------------------------------------------------
 NT_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1000, 2304, 768), (64, 50280, 768), (512, 768, 50280),
-             (1, 8, 8), (4096, 768, 2048)]
+             (1, 8, 8), (4096, 768, 2048), (300, 768, 50304), (130, 136, 192)]
 
 
 @pytest.mark.parametrize('M,N,K', NT_SHAPES)
@@ -312,6 +312,30 @@ def test_cross_entropy(ops, M, V):
   lm = ops.mean(rows)
   assert abs(lm.item() - loss.item()) <= 2e-6 * abs(loss.item()) + 1e-6
   close(buf.float(), leaf.grad, 8e-3, 'dlogits (bf16)')
+
+
+def test_cross_entropy_padded_rows(ops):
+  """Rows padded to a multiple of 64 columns (the lm_head layout): pads must come back as zeros."""
+  M, V, ld = 40, 50280, 50304
+  g = torch.Generator().manual_seed(11)
+  logits = bf(3 * torch.randn(M, V, generator=g))
+  tgt = torch.randint(0, V, (M,), generator=g)
+  leaf = logits.float().requires_grad_(True)
+  loss = O.cross_entropy(leaf, tgt)
+  loss.backward()
+  buf = torch.full((M, ld), 7.0, dtype=torch.bfloat16, device='cuda')
+  buf[:, :V] = logits.cuda()
+  rows = ops.ce_fwd_bwd_(buf, tgt.cuda(), 1.0 / M, V=V)
+  assert abs(ops.mean(rows).item() - loss.item()) <= 2e-6 * abs(loss.item()) + 1e-6
+  close(buf[:, :V].float(), leaf.grad, 8e-3, 'dlogits (padded rows)')
+  assert (buf[:, V:] == 0).all()
+
+
+def test_cast_transpose_padded(ops):
+  x = torch.randn(200, 72, device='cuda')
+  out_t = torch.zeros(72, 256, dtype=torch.bfloat16, device='cuda')
+  y, yt = ops.cast_bf16_t(x, out_t=out_t)
+  assert torch.equal(yt[:, :200], x.bfloat16().t()) and (yt[:, 200:] == 0).all()
 
 
 def test_cross_entropy_golden(ops, golden_dir):
