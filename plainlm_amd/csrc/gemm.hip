@@ -578,9 +578,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 static int tn_splits(int64_t M, int64_t N, int64_t K) {
+  // The DMA kernels run 2 workgroups per CU (512 slots on 256 CUs): aim for just under 2 full rounds.
   const int64_t tiles = plm_cdiv(M, GBM) * plm_cdiv(N, GBN);
-  if (tiles >= 384) return 1;
-  int64_t s = plm_cdiv(768, tiles);
+  if (tiles >= 512) return 1;
+  int64_t s = 1024 / tiles;
   const int64_t max_by_k = K / 512 > 0 ? K / 512 : 1;  // keep >= 512 contraction rows per slab
   if (s > max_by_k) s = max_by_k;
   if (s > 32) s = 32;
