@@ -81,6 +81,13 @@ int plm_swiglu_bwd(const uint16_t* dout, const uint16_t* u, uint16_t* du, int64_
  * fp32 workspace of plm_gemm_tn_workspace_bytes(M,N,K) bytes (0 when no split is used). */
 int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream);
+/* same as plm_gemm_bf16_nt with an explicit kernel choice (autotuning / A-B measurements / tests):
+ * variant 0 = automatic, 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA double-buffered,
+ * 3 = persistent 256x256 4-phase, 4 = persistent 256x128 4-phase (3,4: bf16 C, no accumulate;
+ * 2,3,4: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
+int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
+                        int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
+                        void* stream);
 size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int accumulate, const float* alpha_dev,

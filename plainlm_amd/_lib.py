@@ -36,6 +36,7 @@ SIGNATURES = {
   'plm_swiglu_fwd': (_I, [_P, _P, _I64, _I64, _P]),
   'plm_swiglu_bwd': (_I, [_P, _P, _P, _I64, _I64, _P]),
   'plm_gemm_bf16_nt': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _P]),
+  'plm_gemm_bf16_nt_ex': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _I, _P]),
   'plm_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
   'plm_gemm_bf16_tn': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),

@@ -300,9 +300,14 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const uint16_t* __rest
   }
 }
 
-extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
-                                int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream) {
+bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
+                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s);  // gemm_big.hip
+
+extern "C" int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                   int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
+                                   void* stream) {
   PLM_REQUIRE(A && B && C, "plm_gemm_bf16_nt: null pointer");
+  PLM_REQUIRE(variant >= 0 && variant <= 4, "plm_gemm_bf16_nt_ex: variant must be 0..4");
   PLM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "plm_gemm_bf16_nt: bad shape M=%ld N=%ld K=%ld",
               (long)M, (long)N, (long)K);
   PLM_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "plm_gemm_bf16_nt: K, lda, ldb must be multiples of 8 and ldc of 4 (K=%ld lda=%ld ldb=%ld ldc=%ld)",
@@ -315,7 +320,16 @@ extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* 
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
   hipStream_t s = (hipStream_t)stream;
   static const bool force_v1 = getenv("PLM_GEMM_V1") != nullptr;
-  const bool dma_ok = !force_v1 && (K % GBK == 0) && (N % 8 == 0) && (ldc % 8 == 0);
+  const bool dma_shape = (K % GBK == 0) && (N % 8 == 0) && (ldc % 8 == 0);
+  PLM_REQUIRE(variant <= 1 || dma_shape, "plm_gemm_bf16_nt_ex: variant %d needs K %% 64 == 0, N %% 8 == 0, ldc %% 8 == 0", variant);
+  PLM_REQUIRE(variant <= 2 || c_dtype == 0, "plm_gemm_bf16_nt_ex: the big-tile variants write bf16 C only");
+  const bool dma_ok = variant >= 2 || (variant == 0 && !force_v1 && dma_shape);
+  if ((variant == 0 && dma_ok && c_dtype == 0) || variant >= 3) {
+    if (plm_launch_gemm_nt_big(variant, A, lda, B, ldb, (uint16_t*)C, ldc, M, N, K, alpha_dev, s)) {
+      PLM_CHECK_LAUNCH("plm_gemm_bf16_nt (big tile)");
+      return PLM_OK;
+    }
+  }
 #define PLM_NT_LAUNCH(KERN)                                                                                              \
   hipLaunchKernelGGL(KERN, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tiles_m, tiles_n)
   if (dma_ok) {
@@ -330,6 +344,11 @@ extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* 
 #undef PLM_NT_LAUNCH
   PLM_CHECK_LAUNCH("plm_gemm_bf16_nt");
   return PLM_OK;
+}
+
+extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream) {
+  return plm_gemm_bf16_nt_ex(A, lda, B, ldb, C, ldc, M, N, K, c_dtype, accumulate, alpha_dev, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,277 @@
+// Persistent, deep-pipelined bf16 NT GEMM for gfx950:  C[M,N] (bf16) = alpha * A[M,K] · B[N,K]^T.
+//
+// Why a second NT kernel: with 128x128 tiles one K-step moves 32 KB into LDS per 0.25 us of MFMA work
+// (~33 TB/s chip-wide at full rate = the whole L2 bandwidth), so gemm_nt_dma_kernel is L2-latency /
+// bandwidth bound at 600-1000 TFLOP/s.  This kernel doubles the flops per staged byte and keeps
+// ~1.5 K-tiles of LDS-DMA in flight:
+//
+//   * 256x256 (or 256x128) output tile, 512 threads = 8 waves, wave tile 128x64 (or 64x64) of
+//     v_mfma_f32_32x32x16_bf16 accumulators; ONE workgroup per CU, persistent over tiles
+//     (tile = step * gridDim + xcd_remap(block)), so the DMA stream never drains between tiles.
+//   * The K-tile (BK = 64) of each operand is split into two HALF-TILES chosen so that every wave needs
+//     half h of A and half h of B for quadrant (h_a, h_b) of its accumulators.  A K-tile is consumed in
+//     four phases  (A0,B0) (A0,B1) (A1,B1) (A1,B0);  phase j also issues the LDS-DMA of half-tile j
+//     (order A0,B0,B1,A1) of the NEXT K-tile into the other stage.  Each half-tile therefore has >= 3
+//     phases (>= 24 MFMAs per wave) to land, and a phase ends with a COUNTED s_waitcnt vmcnt(N) that only
+//     waits for the half-tile the next phase reads, then one s_barrier.
+//   * LDS: 2 stages x 4 half-tiles (128-byte rows, XOR swizzle applied on the DMA source address, as in
+//     gemm.hip) + a 4 KiB per-wave epilogue scratch: C leaves as full 128-byte row segments.
+//
+// Requirements (checked by the dispatcher in gemm.hip): bf16 C, no accumulate, K % 64 == 0, N % 8 == 0,
+// 16-byte aligned C rows.
+#include "plm_device.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void big_dma16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int big_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// all of this wave's LDS reads have returned, then the workgroup barrier (never drains VMEM)
+__device__ __forceinline__ void phase_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define BIG_GROUP_M 4
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                             const uint16_t* __restrict__ B, int64_t ldb,
+                                                             uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
+  constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
+  static_assert(WM * WN == 8 && TN == 64 && (TM == 128 || TM == 64), "unsupported geometry");
+  constexpr int AH = TM / 2;                        // rows of one wave's A half
+  constexpr int AF = AH / 32;                       // 32-row MFMA fragments per A half
+  constexpr int A_ROWS = BM / 2, B_ROWS = BN / 2;   // rows per half-tile
+  constexpr int A_HT = A_ROWS * 128, B_HT = B_ROWS * 128;
+  constexpr int STAGE = 2 * A_HT + 2 * B_HT;
+  constexpr int A_DMA = A_ROWS / 64, B_DMA = B_ROWS / 64;  // LDS-DMA instructions per thread per half-tile
+  constexpr int OFF_A0 = 0, OFF_B0 = A_HT, OFF_B1 = A_HT + B_HT, OFF_A1 = A_HT + 2 * B_HT;
+  constexpr int W_P4 = A_DMA + B_DMA;  // end of phase 4: B1', A1' may stay in flight
+  constexpr int W_P1 = 2 * A_DMA;      // end of phase 1: A1', A0'' may stay in flight
+  constexpr int W_P2 = A_DMA + B_DMA;  // end of phase 2: A0'', B0'' may stay in flight
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = K / 64;
+  char* epi = smem + 2 * STAGE + wave * 4096;
+
+  auto coords = [&](int tile, int& m0, int& n0) {
+    const int group_size = BIG_GROUP_M * tiles_n;
+    const int group = tile / group_size;
+    const int first_m = group * BIG_GROUP_M;
+    const int gm = min(tiles_m - first_m, BIG_GROUP_M);
+    const int in_group = tile - group * group_size;
+    m0 = (first_m + in_group % gm) * BM;
+    n0 = (in_group / gm) * BN;
+  };
+
+  // ---- source pointers of the item being staged (one K-tile of one output tile) ----
+  const uint16_t* pa[2][A_DMA];
+  const uint16_t* pb[2][B_DMA];
+  auto set_ptrs = [&](int tile) {
+    int m0, n0;
+    coords(tile, m0, n0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < A_DMA; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = min(m0 + (r / AH) * TM + h * AH + (r % AH), M - 1);
+        pa[h][i] = A + (int64_t)m * lda + chunk * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < B_DMA; ++i) {
+        const int r = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = min(n0 + (r / 32) * TN + h * 32 + (r % 32), N - 1);
+        pb[h][i] = B + (int64_t)n * ldb + chunk * 8;
+      }
+    }
+  };
+  auto issue_a = [&](int h, char* stage, int k0) {
+    char* dst = stage + (h ? OFF_A1 : OFF_A0);
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) big_dma16(pa[h][i] + k0, dst + (i * 8 + wave) * 1024);
+  };
+  auto issue_b = [&](int h, char* stage, int k0) {
+    char* dst = stage + (h ? OFF_B1 : OFF_B0);
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) big_dma16(pb[h][i] + k0, dst + (i * 8 + wave) * 1024);
+  };
+  auto frag = [&](const char* ht, int row, int ks) -> bf16x8_t {
+    return *reinterpret_cast<const bf16x8_t*>(ht + big_swz(row, ks * 2 + hi));
+  };
+
+  const int first = xcd_remap(blockIdx.x, gridDim.x);
+  if (first >= ntiles) return;
+  int s_tile = first, s_k = 0;  // next item to stage
+  set_ptrs(s_tile);
+  auto advance_staged = [&]() {
+    s_k += 64;
+    if (s_k >= K) {
+      s_k = 0;
+      s_tile += gridDim.x;
+      if (s_tile < ntiles) set_ptrs(s_tile);
+    }
+  };
+
+  // read alpha and make the compiler consume it NOW: an ordinary global load still "pending" in hipcc's own
+  // bookkeeping would make it emit a draining s_waitcnt vmcnt(0) at the first use inside the tile loop
+  float alpha = alpha_dev ? *alpha_dev : 1.f;
+  asm volatile("; alpha pinned" : "+v"(alpha));
+
+  // prologue: the first item entirely, into stage 0
+  issue_a(0, smem, s_k);
+  issue_b(0, smem, s_k);
+  issue_b(1, smem, s_k);
+  issue_a(1, smem, s_k);
+  advance_staged();
+  wait_vm<0>();
+  phase_barrier();
+
+  int st = 0;
+  for (int tile = first; tile < ntiles; tile += gridDim.x) {
+    f32x16_t acc[2 * AF][2];
+#pragma unroll
+    for (int i = 0; i < 2 * AF; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = s_tile < ntiles;  // workgroup-uniform
+      const char* cur = smem + st * STAGE;
+      char* nxt = smem + (st ^ 1) * STAGE;
+      bf16x8_t a[AF][4], b0[4], b1[4];
+
+      // ---- phase 1: quadrant (A0, B0); stage A0 of the next item
+      if (more) issue_a(0, nxt, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        b0[ks] = frag(cur + OFF_B0, wn * 32 + l31, ks);
+#pragma unroll
+        for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(b0[ks], a[f][ks], acc[f][0]);
+      if (more) wait_vm<W_P1>(); else wait_vm<0>();
+      phase_barrier();
+
+      // ---- phase 2: quadrant (A0, B1); stage B0
+      if (more) issue_b(0, nxt, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(b1[ks], a[f][ks], acc[f][1]);
+      if (more) wait_vm<W_P2>(); else wait_vm<0>();
+      phase_barrier();
+
+      // ---- phase 3: quadrant (A1, B1); stage B1
+      if (more) issue_b(1, nxt, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A1, wm * AH + f * 32 + l31, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(b1[ks], a[f][ks], acc[AF + f][1]);
+      // phase 4 reads nothing new from LDS (B0 fragments are still in registers): no wait, no barrier here
+
+      // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1
+      if (more) issue_a(1, nxt, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(b0[ks], a[f][ks], acc[AF + f][0]);
+      if (more) {
+        advance_staged();
+        wait_vm<W_P4>();
+      } else {
+        wait_vm<0>();
+      }
+      phase_barrier();
+      st ^= 1;
+    }
+
+    // ---- epilogue: 32-row x 64-col pieces through this wave's private 4 KiB scratch ----
+    int m0, n0;
+    coords(tile, m0, n0);
+#pragma unroll
+    for (int mf = 0; mf < 2 * AF; ++mf) {
+      const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
+          const int c = bh * 4 + g;  // 16-byte chunk of the 64-column row; this lane fills half `hi` of it
+          *reinterpret_cast<bf16x4_t*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4) + hi * 8) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c >> 3, ch = c & 7;
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
+        const int gm = mrow0 + row, gn = n0 + wn * TN + ch * 8;
+        if (gm < M && gn < N) st_bf16x8(C + (int64_t)gm * ldc + gn, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
+static int g_num_cus = 0;
+
+static double round_efficiency(int64_t tiles, int slots) {
+  const int64_t rounds = (tiles + slots - 1) / slots;
+  return (double)tiles / (double)(rounds * slots);
+}
+
+// variant: 0 = pick by tile-count efficiency (may decline), 3 = force 256x256, 4 = force 256x128
+bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
+                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int tm = (int)plm_cdiv(M, 256);
+  const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128);
+  const double e256 = round_efficiency((int64_t)tm * tn256, g_num_cus) * ((double)N / (tn256 * 256.0));
+  const double e128 = round_efficiency((int64_t)tm * tn128, g_num_cus) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
+  if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.7 && e128 < 0.7))) return false;
+  const dim3 block(512);
+  if (variant == 3 || (variant == 0 && e256 >= e128)) {
+    const int ntiles = tm * tn256;
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), dim3(ntiles < g_num_cus ? ntiles : g_num_cus), block, 0, s, A, lda, B, ldb, C,
+                       ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn256);
+  } else {
+    const int ntiles = tm * tn128;
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), dim3(ntiles < g_num_cus ? ntiles : g_num_cus), block, 0, s, A, lda, B, ldb, C,
+                       ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn128);
+  }
+  return true;
+}

@@ -156,8 +156,9 @@ def swiglu_bwd(dout, u):
 
 
 # ---- GEMMs ------------------------------------------------------------------------
-def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None):
-  """C[M,N] = alpha * A[M,K] @ B[N,K]^T ; A, B bf16 (row stride may exceed K)."""
+def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, variant=0):
+  """C[M,N] = alpha * A[M,K] @ B[N,K]^T ; A, B bf16 (row stride may exceed K).
+  variant: 0 auto | 1 128x128 register-staged | 2 128x128 LDS-DMA | 3 persistent 256x256 | 4 persistent 256x128."""
   for t, n in ((A, 'A'), (B, 'B')):
     if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
       raise ValueError(f'gemm_nt.{n}: need a 2-D bf16 GPU tensor with unit inner stride')
@@ -173,8 +174,8 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None):
   if alpha is not None:
     _need(alpha, F32, 'gemm_nt.alpha')
   with _Timed('gemm_nt', 2.0 * M * N * K):
-    _lib.check(_lib.load().plm_gemm_bf16_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
-                                            int(bool(accumulate)), _p(alpha), _stream()), 'plm_gemm_bf16_nt')
+    _lib.check(_lib.load().plm_gemm_bf16_nt_ex(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
+                                               int(bool(accumulate)), _p(alpha), int(variant), _stream()), 'plm_gemm_bf16_nt')
   return out
 
 

@@ -177,6 +177,25 @@ def test_gemm_nt(ops, M, N, K):
   close(acc, 1 + 0.5 * ref, 2e-5 * math.sqrt(K), 'gemm_nt accumulate/alpha')
 
 
+@pytest.mark.parametrize('variant', [2, 3, 4])
+@pytest.mark.parametrize('M,N,K', [(512, 512, 64), (1000, 392, 192), (2048, 768, 768), (8192, 2304, 128), (300, 136, 64),
+                                   (33000, 768, 64)])
+def test_gemm_nt_variants(ops, M, N, K, variant):
+  """Every NT kernel variant incl. the persistent big-tile ones: tails in M and N, one and many K-tiles,
+  more tiles than CUs (several tiles per persistent workgroup, prefetch across tile boundaries)."""
+  g = torch.Generator().manual_seed(M + N + K + variant)
+  A = bf(torch.randn(M, K, generator=g)).cuda()
+  B = bf(torch.randn(N, K, generator=g)).cuda()
+  ref = A.float() @ B.float().t()
+  out = ops.gemm_nt(A, B, variant=variant)
+  close(out.float(), ref, 6e-3, f'gemm_nt variant {variant} {M}x{N}x{K}')
+  alpha = torch.tensor(-0.5, device='cuda')
+  wide = torch.zeros(M, N + 24, dtype=torch.bfloat16, device='cuda')  # padded rows (ldc > N)
+  ops.gemm_nt(A, B, out=wide[:, :N], alpha=alpha, variant=variant)
+  close(wide[:, :N].float(), -0.5 * ref, 6e-3, 'alpha / padded ldc')
+  assert (wide[:, N:] == 0).all()
+
+
 def test_gemm_nt_strided_operand(ops):
   """A is a column block of a wider buffer (the q|k|v and x|z cases)."""
   g = torch.Generator().manual_seed(5)

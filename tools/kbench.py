@@ -36,6 +36,7 @@ def main():
   ap.add_argument('--B', type=int, default=32)
   ap.add_argument('--T', type=int, default=1024)
   ap.add_argument('--json', default='')
+  ap.add_argument('--variants', action='store_true', help='also time every NT kernel variant per shape')
   a = ap.parse_args()
   only = set(a.only.split(',')) if a.only else None
   B, T, d, nh, h, V = a.B, a.T, 768, 12, 2048, 50280
@@ -59,11 +60,14 @@ def main():
     for name, (m, n, k) in {
       'nt qkv fwd': (M, 3 * d, d), 'nt out fwd': (M, d, d), 'nt fc1 fwd': (M, 2 * h, d), 'nt fc2 fwd': (M, d, h),
       'nt head fwd': (M, V, d), 'nt dX qkv': (M, d, 3 * d), 'nt dX fc1': (M, d, 2 * h), 'nt dX fc2': (M, h, d),
-      'nt dX head': (M, d, V)}.items():
+      'nt dX head': (M, d, 50304)}.items():
       A = torch.randn(m, k, device=dev).to(BF)
       Bm = torch.randn(n, k, device=dev).to(BF)
       out = torch.empty(m, n, device=dev, dtype=BF)
       rec(name, timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
+      if k % 64 == 0 and a.variants:
+        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128')):
+          rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
       del A, Bm, out
     for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
                              'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}.items():
