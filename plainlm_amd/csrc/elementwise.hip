@@ -282,27 +282,37 @@ extern "C" int plm_rmsnorm_bwd(const uint16_t* dy, const float* x, const float* 
   return PLM_OK;
 }
 
-// out[j] (+)= sum_r part[r][j]   — rows <= a few thousand, one thread per column
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows,
-                                                     int64_t cols, int accumulate) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[j] (+)= sum_r part[r][j]: one 1024-thread block per 64 columns; thread (g, c) sums rows g, g+16, ... with four
+// independent accumulators (loads stay in flight), then the 16 row groups are combined in LDS in a fixed order.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows,
+                                                      int64_t cols, int accumulate) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int64_t r = 0;
-  for (; r + 3 < rows; r += 4) {
-    s0 += part[r * cols + c];
-    s1 += part[(r + 1) * cols + c];
-    s2 += part[(r + 2) * cols + c];
-    s3 += part[(r + 3) * cols + c];
+  if (col < cols) {
+    int64_t r = g;
+    for (; r + 48 < rows; r += 64) {
+      s0 += part[r * cols + col];
+      s1 += part[(r + 16) * cols + col];
+      s2 += part[(r + 32) * cols + col];
+      s3 += part[(r + 48) * cols + col];
+    }
+    for (; r < rows; r += 16) s0 += part[r * cols + col];
   }
-  for (; r < rows; ++r) s0 += part[r * cols + c];
-  const float s = (s0 + s1) + (s2 + s3);
-  out[c] = accumulate ? out[c] + s : s;
+  red[g][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && col < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][c];
+    out[col] = accumulate ? out[col] + s : s;
+  }
 }
 
 extern "C" int plm_colsum_f32(const float* part, float* out, int64_t rows, int64_t cols, int accumulate, void* stream) {
   PLM_REQUIRE(part && out && rows > 0 && cols > 0, "plm_colsum_f32: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)plm_cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, part, out, rows, cols, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)plm_cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, part, out, rows, cols, accumulate);
   PLM_CHECK_LAUNCH("plm_colsum_f32");
   return PLM_OK;
 }

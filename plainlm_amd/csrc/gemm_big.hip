@@ -38,6 +38,13 @@ __device__ __forceinline__ void phase_barrier() { asm volatile("s_waitcnt lgkmcn
 
 #define BIG_GROUP_M 4
 
+static int g_num_cus = 0;
+
+static double round_efficiency(int64_t tiles, int slots) {
+  const int64_t rounds = (tiles + slots - 1) / slots;
+  return (double)tiles / (double)(rounds * slots);
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
@@ -241,13 +248,236 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   }
 }
 
-// Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
-static int g_num_cus = 0;
+// =============================================================================================
+// TN big tile:  slab[split][i][j] (or C) = sum_{k in split} A[k][i] * B[k][j]   (dW = dY^T X)
+// Same persistent 4-phase pipeline; a work ITEM is (split, 256x256 tile) with its own K range, items of
+// one split are adjacent so the workgroups of an XCD share the split's A/B panels in L2.
+// Half-tile LDS image: [64 k-rows][128 cols] bf16 (256-byte rows, one DMA wave-instruction = 4 rows);
+// the 32-byte column pairs of row k are rotated by 2*(k&3) on the DMA source address so that the
+// ds_read_b64_tr_b16 operand reads (k = token row) are bank-conflict free (see gemm_tn_dma_kernel).
+// =============================================================================================
+template <int MODE>  // 0: C = alpha*acc   1: C += alpha*acc   2: raw partial into slab[split] (ld = N)
+__global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                             const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                             int64_t ldc, int M, int N, int K, int kchunk, int splits,
+                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, WN = 4;
+  constexpr int TM = 128, TN = 64, AH = 64, AF = 2;
+  constexpr int HT = 64 * 256;  // one half-tile: 64 k-rows x 128 cols bf16
+  constexpr int STAGE = 4 * HT;
+  constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT;
+  constexpr int W_ALL = 4;  // A_DMA = B_DMA = 2  ->  every counted wait allows 4 DMA instructions in flight
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
-static double round_efficiency(int64_t tiles, int slots) {
-  const int64_t rounds = (tiles + slots - 1) / slots;
-  return (double)tiles / (double)(rounds * slots);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
+  const int ntiles = tiles_m * tiles_n;
+  const int nitems = ntiles * splits;
+
+  auto coords = [&](int item, int& i0, int& j0, int& kbeg, int& kend, int& split) {
+    split = item / ntiles;
+    const int tile = item - split * ntiles;
+    i0 = (tile / tiles_n) * BM;
+    j0 = (tile % tiles_n) * BN;
+    kbeg = min(K, split * kchunk);
+    kend = min(K, kbeg + kchunk);
+  };
+
+  // DMA lane map: instruction q = i*8 + wave covers k-rows q*4 .. q*4+3; lane -> (row, physical 16-byte chunk)
+  const uint16_t* pa[2][2];
+  const uint16_t* pb[2][2];
+  auto set_ptrs = [&](int item) {
+    int i0, j0, kbeg, kend, split;
+    coords(item, i0, j0, kbeg, kend, split);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * 8 + wave) * 4 + (lane >> 4);
+      const int pp = (lane & 15) >> 1, half16 = lane & 1;
+      const int cb = (pp - 2 * (row & 3)) & 7;   // logical 32-byte pair held at physical position pp
+      const int c = cb * 16 + half16 * 8;        // logical column inside the half-tile (0..127)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ci = i0 + (c / AH) * TM + h * AH + (c % AH);  // A: wave-row group, half, local column
+        const int cj = j0 + (c / 32) * TN + h * 32 + (c % 32);  // B: wave-col group, half, local column
+        pa[h][i] = A + (int64_t)row * lda + min(ci, M - 8);
+        pb[h][i] = B + (int64_t)row * ldb + min(cj, N - 8);
+      }
+    }
+  };
+  auto issue = [&](const uint16_t* const (&p)[2], int64_t ld, char* dst, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) big_dma16(p[i] + (int64_t)k0 * ld, dst + (i * 8 + wave) * 1024);
+  };
+  // operand fragment: 32 logical columns starting at c0 of a half-tile, k-step ks, by two transpose reads
+  auto tr_frag = [&](const char* ht, int c0, int ks) -> bf16x8_t {
+    const int row = ks * 16 + hi * 8 + (t16 >> 2);
+    const char* p = ht + row * 256 + ((((c0 >> 4) + ib) + 2 * (row & 3)) & 7) * 32 + (t16 & 3) * 8;
+    return join_tr(lds_read_tr16(p), lds_read_tr16(p + 4 * 256));
+  };
+
+  const int first = xcd_remap(blockIdx.x, gridDim.x);
+  if (first >= nitems) return;
+  float alpha = (MODE != 2 && alpha_dev) ? *alpha_dev : 1.f;
+  asm volatile("; alpha pinned" : "+v"(alpha));
+
+  // staging cursor: (s_item, s_k) = next K-tile to stage; s_kend = end of that item's K range
+  int s_item = first, s_k = 0, s_kend = 0;
+  auto open_item = [&]() {   // position the cursor on the first K-tile of s_item, skipping empty items
+    while (s_item < nitems) {
+      int i0, j0, kbeg, kend, split;
+      coords(s_item, i0, j0, kbeg, kend, split);
+      if (kend > kbeg) {
+        s_k = kbeg;
+        s_kend = kend;
+        set_ptrs(s_item);
+        return;
+      }
+      s_item += gridDim.x;
+    }
+  };
+  auto advance_staged = [&]() {
+    s_k += 64;
+    if (s_k >= s_kend) {
+      s_item += gridDim.x;
+      open_item();
+    }
+  };
+  open_item();
+  if (s_item < nitems) {
+    issue(pa[0], lda, smem + OFF_A0, s_k);
+    issue(pb[0], ldb, smem + OFF_B0, s_k);
+    issue(pb[1], ldb, smem + OFF_B1, s_k);
+    issue(pa[1], lda, smem + OFF_A1, s_k);
+    advance_staged();
+  }
+  wait_vm<0>();
+  phase_barrier();
+
+  int st = 0;
+  for (int item = first; item < nitems; item += gridDim.x) {
+    int i0, j0, kbeg, kend, split;
+    coords(item, i0, j0, kbeg, kend, split);
+    f32x16_t acc[2 * AF][2];
+#pragma unroll
+    for (int i = 0; i < 2 * AF; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg) / 64;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = s_item < nitems;  // workgroup-uniform
+      const char* cur = smem + st * STAGE;
+      char* nxt = smem + (st ^ 1) * STAGE;
+      bf16x8_t a[AF][4], b0[4], b1[4];
+
+      if (more) issue(pa[0], lda, nxt + OFF_A0, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        b0[ks] = tr_frag(cur + OFF_B0, wn * 32, ks);
+#pragma unroll
+        for (int f = 0; f < AF; ++f) a[f][ks] = tr_frag(cur + OFF_A0, wm * AH + f * 32, ks);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(a[f][ks], b0[ks], acc[f][0]);
+      if (more) wait_vm<W_ALL>(); else wait_vm<0>();
+      phase_barrier();
+
+      if (more) issue(pb[0], ldb, nxt + OFF_B0, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(cur + OFF_B1, wn * 32, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(a[f][ks], b1[ks], acc[f][1]);
+      if (more) wait_vm<W_ALL>(); else wait_vm<0>();
+      phase_barrier();
+
+      if (more) issue(pb[1], ldb, nxt + OFF_B1, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) a[f][ks] = tr_frag(cur + OFF_A1, wm * AH + f * 32, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(a[f][ks], b1[ks], acc[AF + f][1]);
+
+      if (more) issue(pa[1], lda, nxt + OFF_A1, s_k);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(a[f][ks], b0[ks], acc[AF + f][0]);
+      if (more) {
+        advance_staged();
+        wait_vm<W_ALL>();
+      } else {
+        wait_vm<0>();
+      }
+      phase_barrier();
+      st ^= 1;
+    }
+
+    // epilogue: D[i][j], lane owns column j = l31, 16 rows per accumulator; 128-byte row segments per half-wave
+    float* out = (MODE == 2) ? C + (int64_t)split * M * N : C;
+    const int64_t ld = (MODE == 2) ? N : ldc;
+#pragma unroll
+    for (int mf = 0; mf < 2 * AF; ++mf) {
+      const int row0 = i0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh) {
+        const int col = j0 + wn * TN + bh * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + mfma32_row(r, hi);
+          if (row >= M) continue;
+          float* dst = out + (int64_t)row * ld + col;
+          const float v = acc[mf][bh][r] * alpha;
+          *dst = (MODE == 1) ? *dst + v : v;
+        }
+      }
+    }
+  }
 }
+
+// chooses the split count for the big TN kernel; 0 = do not use it
+int plm_tn_big_splits(int64_t M, int64_t N, int64_t K) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (K % 64 != 0 || M < 256 || N < 256) return 0;
+  const int64_t tiles = plm_cdiv(M, 256) * plm_cdiv(N, 256);
+  if (tiles >= g_num_cus) return round_efficiency(tiles, g_num_cus) >= 0.85 ? 1 : 0;
+  int64_t s = g_num_cus / tiles;
+  const int64_t max_by_k = K / 512 > 0 ? K / 512 : 1;  // >= 8 K-tiles per item
+  if (s > max_by_k) s = max_by_k;
+  return (int)(s < 1 ? 1 : s);
+}
+
+void plm_launch_gemm_tn_big(int mode, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C,
+                            int64_t ldc, int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s) {
+  const int tm = (int)plm_cdiv(M, 256), tn = (int)plm_cdiv(N, 256);
+  const int kchunk = (int)(plm_cdiv(plm_cdiv(K, splits), 64) * 64);
+  const int nitems = tm * tn * splits;
+  const dim3 grid(nitems < g_num_cus ? nitems : g_num_cus), block(512);
+#define PLM_TNB(MODE_) \
+  hipLaunchKernelGGL(gemm_tn_big_kernel<MODE_>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, splits, alpha_dev, tm, tn)
+  if (mode == 0) PLM_TNB(0);
+  else if (mode == 1) PLM_TNB(1);
+  else PLM_TNB(2);
+#undef PLM_TNB
+}
+
+// Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
 // variant: 0 = pick by tile-count efficiency (may decline), 3 = force 256x256, 4 = force 256x128
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,

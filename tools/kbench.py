@@ -75,6 +75,10 @@ def main():
       Bm = torch.randn(k, n, device=dev).to(BF)
       out = torch.zeros(m, n, device=dev)
       rec(name, timeit(lambda: ops.gemm_tn(A, Bm, out=out, accumulate=True), a.iters), flops=2.0 * m * n * k)
+      if a.variants:
+        os.environ['PLM_TN_NO_BIG'] = '1'
+        rec(name + ' [dma128]', timeit(lambda: ops.gemm_tn(A, Bm, out=out, accumulate=True), a.iters), flops=2.0 * m * n * k)
+        del os.environ['PLM_TN_NO_BIG']
       del A, Bm, out
 
   if want('attn'):
