@@ -19,6 +19,10 @@
 //
 // Requirements (checked by the dispatcher in gemm.hip): bf16 C, no accumulate, K % 64 == 0, N % 8 == 0,
 // 16-byte aligned C rows.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "plm_device.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -45,7 +49,10 @@ static double round_efficiency(int64_t tiles, int slots) {
   return (double)tiles / (double)(rounds * slots);
 }
 
-template <int BM, int BN, int WM, int WN>
+// STAG: every phase is split into a READ section (DMA issue, ds_reads, counted vmcnt wait) and an MFMA section with a
+// barrier after each; the wave group wm-odd runs one barrier behind the other (waves w and w+4 share a SIMD and sit in
+// different groups), so one group's LDS reads overlap the other group's MFMAs; s_setprio(1) around the MFMA cluster.
+template <int BM, int BN, int WM, int WN, bool STAG>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   advance_staged();
   wait_vm<0>();
   phase_barrier();
+  if (STAG && (wm & 1)) phase_barrier();  // odd wave group runs one barrier behind
 
   int st = 0;
   for (int tile = first; tile < ntiles; tile += gridDim.x) {
@@ -163,6 +171,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[4], b1[4];
 
+      // end of a phase's READ section / MFMA section
+      auto end_read = [&](auto wtag) {
+        constexpr int W = decltype(wtag)::value;
+        if (more) wait_vm<W>(); else wait_vm<0>();
+        phase_barrier();
+        if (STAG) __builtin_amdgcn_s_setprio(1);
+      };
+      auto end_mfma = [&]() {
+        if (STAG) {
+          __builtin_amdgcn_s_setprio(0);
+          phase_barrier();
+        }
+      };
+      using std::integral_constant;
+
       // ---- phase 1: quadrant (A0, B0); stage A0 of the next item
       if (more) issue_a(0, nxt, s_k);
 #pragma unroll
@@ -171,49 +194,56 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
       }
+      if (STAG) end_read(integral_constant<int, W_P1>{});
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(b0[ks], a[f][ks], acc[f][0]);
-      if (more) wait_vm<W_P1>(); else wait_vm<0>();
-      phase_barrier();
+      if (STAG) end_mfma(); else end_read(integral_constant<int, W_P1>{});
 
       // ---- phase 2: quadrant (A0, B1); stage B0
       if (more) issue_b(0, nxt, s_k);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
+      if (STAG) end_read(integral_constant<int, W_P2>{});
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(b1[ks], a[f][ks], acc[f][1]);
-      if (more) wait_vm<W_P2>(); else wait_vm<0>();
-      phase_barrier();
+      if (STAG) end_mfma(); else end_read(integral_constant<int, W_P2>{});
 
-      // ---- phase 3: quadrant (A1, B1); stage B1
+      // ---- phase 3: quadrant (A1, B1); stage B1.  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
       if (more) issue_b(1, nxt, s_k);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A1, wm * AH + f * 32 + l31, ks);
+      if (STAG) {
+        phase_barrier();
+        __builtin_amdgcn_s_setprio(1);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(b1[ks], a[f][ks], acc[AF + f][1]);
-      // phase 4 reads nothing new from LDS (B0 fragments are still in registers): no wait, no barrier here
+      if (STAG) end_mfma();
 
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1
       if (more) issue_a(1, nxt, s_k);
+      if (STAG) {
+        if (more) advance_staged();
+        end_read(integral_constant<int, W_P4>{});
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(b0[ks], a[f][ks], acc[AF + f][0]);
-      if (more) {
-        advance_staged();
-        wait_vm<W_P4>();
+      if (STAG) {
+        end_mfma();
       } else {
-        wait_vm<0>();
+        if (more) advance_staged();
+        end_read(integral_constant<int, W_P4>{});
       }
-      phase_barrier();
       st ^= 1;
     }
 
@@ -246,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
+  if (STAG && !(wm & 1)) phase_barrier();  // balances the extra barrier of the odd group
 }
 
 // =============================================================================================
@@ -479,7 +510,7 @@ void plm_launch_gemm_tn_big(int mode, int splits, const uint16_t* A, int64_t lda
 
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
-// variant: 0 = pick by tile-count efficiency (may decline), 3 = force 256x256, 4 = force 256x128
+// variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s) {
   if (g_num_cus == 0) {
@@ -494,14 +525,18 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const double e128 = round_efficiency((int64_t)tm * tn128, g_num_cus) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.7 && e128 < 0.7))) return false;
   const dim3 block(512);
-  if (variant == 3 || (variant == 0 && e256 >= e128)) {
-    const int ntiles = tm * tn256;
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), dim3(ntiles < g_num_cus ? ntiles : g_num_cus), block, 0, s, A, lda, B, ldb, C,
-                       ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn256);
+  static const bool auto_stag = getenv("PLM_GEMM_NO_STAG") == nullptr;
+  const bool use256 = variant == 3 || variant == 5 || (variant == 0 && e256 >= e128);
+  const bool stag = variant >= 5 || (variant == 0 && auto_stag);
+  const int ntiles = tm * (use256 ? tn256 : tn128);
+  const dim3 grid(ntiles < g_num_cus ? ntiles : g_num_cus);
+#define PLM_NTB(BN_, WM_, WN_, ST_, TN_) \
+  hipLaunchKernelGGL((gemm_nt_big_kernel<256, BN_, WM_, WN_, ST_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, TN_)
+  if (use256) {
+    if (stag) PLM_NTB(256, 2, 4, true, tn256); else PLM_NTB(256, 2, 4, false, tn256);
   } else {
-    const int ntiles = tm * tn128;
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), dim3(ntiles < g_num_cus ? ntiles : g_num_cus), block, 0, s, A, lda, B, ldb, C,
-                       ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn128);
+    if (stag) PLM_NTB(128, 4, 2, true, tn128); else PLM_NTB(128, 4, 2, false, tn128);
   }
+#undef PLM_NTB
   return true;
 }
