@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const uint16_t* __rest
     char* dB = dA + GBK * GBM * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      dma16(a_src[i] + (int64_t)k0 * lda, dA + (i * 4 + wave) * 1024);
-      dma16(b_src[i] + (int64_t)k0 * ldb, dB + (i * 4 + wave) * 1024);
+      dma16_asm(a_src[i] + (int64_t)k0 * lda, dA + (i * 4 + wave) * 1024);
+      dma16_asm(b_src[i] + (int64_t)k0 * ldb, dB + (i * 4 + wave) * 1024);
     }
   };
   auto tr_frag = [&](const char* base, int cb0, int ks) -> bf16x8_t {

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   };
   auto issue = [&](const uint16_t* const (&p)[2], int64_t ld, char* dst, int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) big_dma16(p[i] + (int64_t)k0 * ld, dst + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) dma16_asm(p[i] + (int64_t)k0 * ld, dst + (i * 8 + wave) * 1024);
   };
   // operand fragment: 32 logical columns starting at c0 of a half-tile, k-step ks, by two transpose reads
   auto tr_frag = [&](const char* ht, int c0, int ks) -> bf16x8_t {
@@ -525,7 +525,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const double e128 = round_efficiency((int64_t)tm * tn128, g_num_cus) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.7 && e128 < 0.7))) return false;
   const dim3 block(512);
-  static const bool auto_stag = getenv("PLM_GEMM_NO_STAG") == nullptr;
+  static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default
   const bool use256 = variant == 3 || variant == 5 || (variant == 0 && e256 >= e128);
   const bool stag = variant >= 5 || (variant == 0 && auto_stag);
   const int ntiles = tm * (use256 ? tn256 : tn128);

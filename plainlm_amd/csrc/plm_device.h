@@ -95,6 +95,23 @@ __device__ __forceinline__ bf16x8_t join_tr(s16x4_t lo, s16x4_t hi) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// LDS-DMA (global_load_lds_dwordx4) issued through inline asm: 16 bytes per lane from `gsrc` land at
+// lds_wave_base + lane*16 (wave-uniform base).  Unlike the builtin, hipcc does not see an LDS write here, so it does
+// not put a draining s_waitcnt vmcnt(0) in front of later LDS reads it cannot disambiguate (it did so before every
+// ds_read_b64_tr_b16).  The caller owns the ordering: counted s_waitcnt vmcnt(N), then a barrier, then the reads.
+// No VGPR destination, so the statement is register-safe; M0 is saved and restored inside the statement.
+__device__ __forceinline__ unsigned lds_addr_u32(const void* p) {
+  return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) void*)p);
+}
+__device__ __forceinline__ void dma16_asm(const void* gsrc, const void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds_wave_base));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive ids on one XCD
 // (hardware places workgroup b on XCD b % 8) so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
