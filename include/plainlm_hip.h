@@ -93,15 +93,20 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
                      int64_t M, int64_t N, int64_t K, int accumulate, const float* alpha_dev,
                      void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- causal / document-masked attention with in-kernel RoPE
+/* ---- RoPE + causal / document-masked attention
  * (models/transformer.py:43-65, models/embeddings.py:15-30, data/datasets/data_prep_utils.py:7-23)
- * qkv bf16[B*T, 3*nh*hd] straight from w_qkv (q | k | v column blocks, head h = cols h*hd..), hd == 64.
+ * qkv bf16[B*T, 3*nh*hd] straight from w_qkv (q | k | v column blocks, head h = cols h*hd..), hd == 64, T % 4 == 0.
  * rope_cos/sin fp32[T, hd/2] (interleaved-pair convention).  doc_start int32[B,T] or NULL (pure causal):
- * query i attends key j iff doc_start[i] <= j <= i.
- * fwd: out bf16[B*T, nh*hd], lse fp32[B, nh, T] (natural-log LSE of the scaled scores)
- * bwd: dqkv bf16[B*T, 3*nh*hd] (gradient w.r.t. the PRE-rotation q,k and v); delta fp32[B,nh,T] scratch. */
-int plm_attn_fwd(const uint16_t* qkv, const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
-                 uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream);
+ * query i attends key j iff doc_start[i] <= j <= i (doc_start non-decreasing in i).
+ * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (once per layer; fp32 math, bf16 result).
+ * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (natural-log LSE of the
+ *               scaled scores).  No transposed / contiguous copies of q, k, v are made anywhere.
+ * plm_attn_bwd: same rotated qkv; dqkv bf16[B*T, 3*nh*hd] = gradient w.r.t. the PRE-rotation q, k (the inverse
+ *               rotation is applied in the kernels' epilogues) and v; delta fp32[B,nh,T] scratch. */
+int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
+                void* stream);
+int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,
+                 int64_t hd, void* stream);
 int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
                  const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
                  uint16_t* dqkv, float* delta, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream);

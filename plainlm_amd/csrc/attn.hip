@@ -11,11 +11,10 @@
 // token row are fetched with ds_read_b64_tr_b16 (hardware transpose) from the same LDS image that
 // serves the ds_read_b128 operands.
 //
-// LDS image of a [R rows][64 d] bf16 tile ("swizzled sub-tiles"):
-//   byte(row, d) = (d>>4)*(R*32+128) + row*32 + ((((d>>3)&1) ^ ((row>>3)&1))<<4) + (d&7)*2
-// 16-column sub-tiles make a transpose-read block (4 rows x 32 B) contiguous; the 128-byte pad puts the
-// two sub-tiles touched by one 32-lane half on different bank halves; the (row>>3)&1 swizzle of the
-// 16-byte halves makes ds_read_b128 across rows r and r+8 conflict-free.
+// RoPE is applied ONCE per layer to the q|k blocks of the projection output (rope_qk_kernel, in place), so no
+// inner loop rotates anything; K/V (fwd, dQ) and Q/dO (dK/dV) tiles are staged global -> LDS by LDS-DMA into
+// two LDS stages with one barrier per tile (no VGPR round trip, no ds_write); the backward kernels apply the
+// inverse rotation to dQ / dK in their epilogues, so dqkv is the gradient w.r.t. the PRE-rotation projection.
 #include "plm_device.h"
 
 #include <type_traits>
@@ -25,11 +24,6 @@
 
 // raw v_exp_f32: arguments here are <= 0 (or -inf), so no denormal-range fix-up is needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-template <int R>
-__device__ __forceinline__ int tile_off(int row, int d) {
-  return (d >> 4) * (R * 32 + 128) + row * 32 + ((((d >> 3) & 1) ^ ((row >> 3) & 1)) << 4) + (d & 7) * 2;
-}
 
 // interleaved-pair rotation of 8 consecutive head dims (4 pairs); sgn = +1 forward, -1 inverse (gradient)
 __device__ __forceinline__ bf16x8_t rope8(bf16x8_t v, f32x4_t c, f32x4_t s, float sgn) {
@@ -44,33 +38,67 @@ __device__ __forceinline__ bf16x8_t rope8(bf16x8_t v, f32x4_t c, f32x4_t s, floa
   return o;
 }
 
-// staging map of a [64 rows][64 d] tile over 256 threads, 2 chunks (16 B) each: an 8-lane store group
-// covers 2 rows x 4 chunks (2 sub-tiles) = 8 distinct 16-byte slots mod 256 (conflict-free ds_write_b128)
-__device__ __forceinline__ void stage_map(int idx, int& row, int& chunk) {
-  const int u = idx & 7, rest = idx >> 3;
-  chunk = (rest & 1) * 4 + (u & 3);
-  row = ((rest >> 1) << 1) | (u >> 2);
+// ---------------------------------------------------------------------------------------------
+// LDS image of a [rows][64 d] bf16 tile: row-major, 128-byte rows (so one LDS-DMA wave-instruction =
+// 8 whole rows = 8 fully used 128-byte global segments).  Inside row r (bits b0..b3) the logical 16-byte
+// chunk c = 2*pair + half is stored at pair' = (pair + 2*b1 + b3) & 3, half' = half ^ b2:
+//   * ds_read_b128 of one chunk across 16 rows (r mod 16 distinct) hits 16 different 16-byte slots of
+//     the 256-byte bank row (b0 picks the 128-byte half, (b1,b3) the pair, b2 the half): conflict-free;
+//   * ds_read_b64_tr_b16 of a [4 rows][16 cols] block (rows R..R+3, R % 4 == 0) puts the four rows on
+//     four different 32-byte segments, and the neighbouring 16-column block on the other four.
+// The permutation is applied on the DMA SOURCE address (the DMA itself writes lane-linear).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rs_off(int row, int c) {
+  const int pp = ((c >> 1) + 2 * ((row >> 1) & 1) + ((row >> 3) & 1)) & 3;
+  const int ph = (c & 1) ^ ((row >> 2) & 1);
+  return row * 128 + pp * 32 + ph * 16;
+}
+__device__ __forceinline__ int rs_logical_chunk(int row, int pc) {  // inverse: physical chunk pc of row -> logical chunk
+  const int cb = ((pc >> 1) - 2 * ((row >> 1) & 1) - ((row >> 3) & 1)) & 3;
+  return cb * 2 + ((pc & 1) ^ ((row >> 2) & 1));
 }
 
 // A-operand fragment (rows i = tile rows, k = head dims ks*16 + hi*8 ..) by ds_read_b128
-template <int R>
 __device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row, int ks, int hi) {
-  return *reinterpret_cast<const bf16x8_t*>(tile + tile_off<R>(row, ks * 16 + hi * 8));
+  return *reinterpret_cast<const bf16x8_t*>(tile + rs_off(row, ks * 2 + hi));
 }
 // A-operand fragment (rows i = head dims db*32 + (lane&31), k = tile rows) by two transpose reads.
 // k-slot e of lane-half hi maps to tile row  rbase + (e&3) + 8*(e>>2)  — the row order in which a lane
 // holds the matching B operand after a transposed-score MFMA (see mfma32_row()).
-template <int R>
 __device__ __forceinline__ bf16x8_t frag_cols(const char* tile, int db, int rbase, int lane) {
   const int ib = (lane >> 4) & 1, t16 = lane & 15;
+  const int sub = t16 & 3;                 // 8-byte piece of the 32-byte (16-column) block
+  const int c = (db * 2 + ib) * 2 + (sub >> 1);
   const int row = rbase + (t16 >> 2);
-  const int sub = db * 2 + ib;
-  const int half = (t16 & 3) >> 1;
-  const char* p0 = tile + sub * (R * 32 + 128) + row * 32 + ((half ^ ((row >> 3) & 1)) << 4) + (t16 & 1) * 8;
-  const int row1 = row + 8;
-  const char* p1 = tile + sub * (R * 32 + 128) + row1 * 32 + ((half ^ ((row1 >> 3) & 1)) << 4) + (t16 & 1) * 8;
+  const char* p0 = tile + rs_off(row, c) + (sub & 1) * 8;
+  const char* p1 = tile + rs_off(row + 8, c) + (sub & 1) * 8;
   return join_tr(lds_read_tr16(p0), lds_read_tr16(p1));
 }
+
+// LDS-DMA of a [64 rows][64 d] tile (8 KiB = 8 wave-instructions, two per wave).  `src` points at (row 0, d 0) of
+// the tile in global memory, `ld` is the row stride in elements; rows above `last_row` are clamped (their values are
+// masked out by the caller).
+struct TileDma {
+  int row[2], coff[2];
+  __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      row[i] = (i * 4 + wave) * 8 + (lane >> 3);
+      coff[i] = rs_logical_chunk(row[i], lane & 7) * 8;
+    }
+  }
+  __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      dma16_asm(src + (int64_t)min(row[i], last_row) * ld + coff[i], dst_tile + (i * 4 + wave) * 1024);
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void attn_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void attn_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void zero16(f32x16_t& v) {
 #pragma unroll
@@ -78,22 +106,46 @@ __device__ __forceinline__ void zero16(f32x16_t& v) {
 }
 
 // =============================================================================================
-// forward
+// RoPE on the q and k column blocks of the w_qkv output, in place (models/embeddings.py:15-30):
+// interleaved pairs (x[2i], x[2i+1]) -> (a cos - b sin, b cos + a sin), fp32 math, bf16 result.
+// Runs once per layer right after the projection, so no inner loop ever rotates anything again
+// (the backward kernels apply the inverse rotation to dQ / dK in their epilogues).
+// =============================================================================================
+__global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
+                                                      const float* __restrict__ rsin, int64_t BT, int T, int nh) {
+  const int dm = nh * HD, ld = 3 * dm;
+  const int cpr = 2 * dm / 8;  // 16-byte chunks of q|k per token row
+  const int64_t total = BT * cpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = i / cpr;
+    const int c = (int)(i - row * cpr);
+    const int t = (int)(row % T);
+    const int pair0 = (c * 8 % HD) / 2;
+    uint16_t* p = qkv + row * ld + c * 8;
+    const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + t * (HD / 2) + pair0);
+    const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + t * (HD / 2) + pair0);
+    st_bf16x8(p, rope8(ld_bf16x8(p), cs, sn, 1.f));
+  }
+}
+
+// =============================================================================================
+// forward (q, k already rotated)
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
-                                                       const float* __restrict__ rsin, const int32_t* __restrict__ doc_start,
-                                                       uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
-  constexpr int KT = 64;  // kv rows per tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (KT * 32 + 128)];
-  char* sK = smem;
-  char* sV = smem + 4 * (KT * 32 + 128);
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
+                                                          uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
+  constexpr int KT = 64;            // kv rows per tile
+  constexpr int TILE = KT * 128;    // 8 KiB
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE];  // [stage][K|V]
 
   const int nqt = gridDim.x;
   const int qt = nqt - 1 - blockIdx.x;  // heaviest (latest) query tiles first
   const int h = blockIdx.y, b = blockIdx.z;
   const int dm = nh * HD, ld = 3 * dm;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
   const int q0 = qt * 128;
   const int qw0 = q0 + wave * 32;
   const int qrow = qw0 + l31;
@@ -104,18 +156,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 
   bf16x8_t qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int d0 = ks * 16 + hi * 8;
-    qf[ks] = zero_bf16x8();
-    if (qvalid) {
-      const bf16x8_t raw = ld_bf16x8(base + (int64_t)qrow * ld + d0);
-      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + qrow * 32 + d0 / 2);
-      const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + qrow * 32 + d0 / 2);
-      qf[ks] = rope8(raw, cs, sn, 1.f);
-    }
-  }
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
   int dsq = 0;
   if (HAS_DOC && qvalid) dsq = doc_start[(int64_t)b * T + qrow];
+  asm volatile("; q fragments resident" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(dsq));  // consumed before any DMA is in flight
 
   f32x16_t o[2];
   zero16(o[0]);
@@ -125,48 +170,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   const int kv_hi = min(T, q0 + 128);
   const int jt_hi = (kv_hi + KT - 1) / KT;
   int jt_lo = 0;
-  if (HAS_DOC) jt_lo = doc_start[(int64_t)b * T + q0] / KT;
+  if (HAS_DOC) jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
 
-  // staging registers (next tile in flight during compute)
-  int srow[2], schunk[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
-  bf16x8_t rk[2], rv[2];
-  f32x4_t rc[2], rs[2];
-  auto g_load = [&](int kv0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kv = kv0 + srow[i];
-      rk[i] = zero_bf16x8();
-      rv[i] = zero_bf16x8();
-      rc[i] = f32x4_t{1.f, 1.f, 1.f, 1.f};
-      rs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (kv < T) {
-        const uint16_t* p = base + (int64_t)kv * ld + schunk[i] * 8;
-        rk[i] = ld_bf16x8(p + dm);
-        rv[i] = ld_bf16x8(p + 2 * dm);
-        rc[i] = *reinterpret_cast<const f32x4_t*>(rcos + kv * 32 + schunk[i] * 4);
-        rs[i] = *reinterpret_cast<const f32x4_t*>(rsin + kv * 32 + schunk[i] * 4);
-      }
-    }
-  };
-  auto s_store = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = tile_off<KT>(srow[i], schunk[i] * 8);
-      *reinterpret_cast<bf16x8_t*>(sK + off) = rope8(rk[i], rc[i], rs[i], 1.f);
-      *reinterpret_cast<bf16x8_t*>(sV + off) = rv[i];
-    }
-  };
-
-  if (jt_lo < jt_hi) {
-    g_load(jt_lo * KT);
-    s_store();
-  }
-  __syncthreads();
-  for (int jt = jt_lo; jt < jt_hi; ++jt) {
+  TileDma dma;
+  dma.init(wave, lane);
+  auto stage = [&](int st, int jt) {
     const int kv0 = jt * KT;
-    if (jt + 1 < jt_hi) g_load((jt + 1) * KT);
+    const uint16_t* src = base + (int64_t)kv0 * ld;
+    dma.issue(smem + st * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+    dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+  };
+
+  if (jt_lo < jt_hi) stage(0, jt_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  int st = 0;
+  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) {
+    const int kv0 = jt * KT;
+    if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
+    const char* sK = smem + st * 2 * TILE;
+    const char* sV = sK + TILE;
     const bool wave_active = kv0 <= qw0 + 31;  // tile not entirely above this wave's diagonal
     if (wave_active) {
       f32x16_t s[2];
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
       for (int kb = 0; kb < 2; ++kb) {
         zero16(s[kb]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s[kb]);
+        for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows(sK, kb * 32 + l31, ks, hi), qf[ks], s[kb]);
       }
       // masking is only needed on tiles that touch the diagonal (or always with document masks)
       auto softmax_pv = [&](auto mask_tag) {
@@ -222,18 +245,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
           for (int sp = 0; sp < 4; ++sp) {
             const int rbase = (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi;
-            o[db] = mfma32(frag_cols<KT>(sV, db, rbase, lane), pf[sp], o[db]);
+            o[db] = mfma32(frag_cols(sV, db, rbase, lane), pf[sp], o[db]);
           }
         }
       };
       if (HAS_DOC || (kv0 + KT - 1 > qw0)) softmax_pv(std::true_type{});
       else softmax_pv(std::false_type{});
     }
-    __syncthreads();
-    if (jt + 1 < jt_hi) {
-      s_store();
-      __syncthreads();
-    }
+    attn_wait_vm<0>();  // next tile landed (this wave's pieces) ...
+    attn_barrier();     // ... everyone's; and every wave is done reading the current stage
   }
 
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -279,25 +299,24 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
 }
 
 // =============================================================================================
-// backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows)
+// backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows; q, k rotated)
 // =============================================================================================
 template <bool HAS_DOC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                            const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv,
-                                                            int T, int nh) {
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                               const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv,
+                                                               int T, int nh) {
   constexpr int QT = 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (QT * 32 + 128) + 3 * QT * 4];
-  char* sQ = smem;
-  char* sDO = smem + 4 * (QT * 32 + 128);
-  float* sL = reinterpret_cast<float*>(smem + 2 * 4 * (QT * 32 + 128));  // lse * log2(e)
-  float* sD = sL + QT;
-  int* sDS = reinterpret_cast<int*>(sD + QT);
+  constexpr int TILE = QT * 128;           // 8 KiB
+  constexpr int STAGE = 2 * TILE + 1024;   // Q | dO | statistics (lse[64], delta[64], doc_start[64])
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int dm = nh * HD, ld = 3 * dm;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
   const int kv0 = kt * 128;
   const int kvw0 = kv0 + wave * 32;
   const int kvrow = kvw0 + l31;
@@ -312,24 +331,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   bf16x8_t kf[4], vf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const int d0 = ks * 16 + hi * 8;
-    kf[ks] = zero_bf16x8();
-    vf[ks] = zero_bf16x8();
-    if (kvalid) {
-      const uint16_t* p = base + (int64_t)kvrow * ld + d0;
-      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + kvrow * 32 + d0 / 2);
-      const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + kvrow * 32 + d0 / 2);
-      kf[ks] = rope8(ld_bf16x8(p + dm), cs, sn, 1.f);
-      vf[ks] = ld_bf16x8(p + 2 * dm);
-    }
+    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
+    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
+    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
   }
-  f32x16_t dk[2], dv[2];
-  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
-
-  int srow[2], schunk[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
-
   // query-tile range: from the diagonal down; with document masks stop once a tile's first row starts
   // after this key block (doc_start is non-decreasing)
   const int nqt = (T + QT - 1) / QT;
@@ -337,56 +342,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   int jq_hi = nqt;
   if (HAS_DOC) {
     jq_hi = jq_lo;
-    while (jq_hi < nqt && dsrow[jq_hi * QT] <= kv0 + 127) ++jq_hi;
+    while (jq_hi < nqt && __builtin_amdgcn_readfirstlane(dsrow[jq_hi * QT]) <= kv0 + 127) ++jq_hi;
   }
+  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
+               "v"(vf[3]));  // every ordinary load is consumed before the first DMA is in flight
 
-  bf16x8_t rq[2], rdo[2];
-  float rL = 0.f, rD = 0.f;
-  int rDS = 0;
-  auto g_load = [&](int qt0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = qt0 + srow[i];
-      rq[i] = zero_bf16x8();
-      rdo[i] = zero_bf16x8();
-      if (q < T) {
-        rq[i] = ld_bf16x8(base + (int64_t)q * ld + schunk[i] * 8);
-        rdo[i] = ld_bf16x8(dobase + (int64_t)q * dm + schunk[i] * 8);
-      }
-    }
-    if (t < QT) {
-      const int q = qt0 + t;
-      rL = (q < T) ? lrow[q] * LOG2E : 0.f;
-      rD = (q < T) ? drow[q] : 0.f;
-      rDS = (HAS_DOC && q < T) ? dsrow[q] : 0;
-    }
-  };
-  auto s_store = [&](int qt0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = tile_off<QT>(srow[i], schunk[i] * 8);
-      // the rotation table is tiny and L2-resident: fetched here rather than held across the MFMA phase
-      const int q = min(qt0 + srow[i], T - 1);
-      const f32x4_t rc = *reinterpret_cast<const f32x4_t*>(rcos + q * 32 + schunk[i] * 4);
-      const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(rsin + q * 32 + schunk[i] * 4);
-      *reinterpret_cast<bf16x8_t*>(sQ + off) = rope8(rq[i], rc, rs, 1.f);
-      *reinterpret_cast<bf16x8_t*>(sDO + off) = rdo[i];
-    }
-    if (t < QT) {
-      sL[t] = rL;
-      sD[t] = rD;
-      sDS[t] = rDS;
-    }
-  };
+  f32x16_t dk[2], dv[2];
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
 
-  if (jq_lo < jq_hi) {
-    g_load(jq_lo * QT);
-    s_store(jq_lo * QT);
-  }
-  __syncthreads();
-  for (int jq = jq_lo; jq < jq_hi; ++jq) {
+  TileDma dma;
+  dma.init(wave, lane);
+  auto stage = [&](int st, int jq) {
     const int qt0 = jq * QT;
-    if (jq + 1 < jq_hi) g_load((jq + 1) * QT);
+    char* dst = smem + st * STAGE;
+    dma.issue(dst, base + (int64_t)qt0 * ld, ld, T - 1 - qt0, wave);
+    dma.issue(dst + TILE, dobase + (int64_t)qt0 * dm, dm, T - 1 - qt0, wave);
+    if (wave == 0 && lane < 16) {  // 64 floats = 16 lanes x 16 bytes per statistic (T % 4 == 0 is checked on the host)
+      const int q = min(qt0 + lane * 4, T - 4);
+      dma16_asm(lrow + q, dst + 2 * TILE);
+      dma16_asm(drow + q, dst + 2 * TILE + 256);
+      if (HAS_DOC) dma16_asm(dsrow + q, dst + 2 * TILE + 512);
+    }
+  };
+
+  if (jq_lo < jq_hi) stage(0, jq_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  int st = 0;
+  for (int jq = jq_lo; jq < jq_hi; ++jq, st ^= 1) {
+    const int qt0 = jq * QT;
+    if (jq + 1 < jq_hi) stage(st ^ 1, jq + 1);
+    const char* sQ = smem + st * STAGE;
+    const char* sDO = sQ + TILE;
+    const float* sL = reinterpret_cast<const float*>(sQ + 2 * TILE);
+    const float* sD = sL + 64;
+    const int* sDS = reinterpret_cast<const int*>(sL + 128);
     const bool wave_active = qt0 + QT - 1 >= kvw0;  // some query at or below this wave's first key
     if (wave_active) {
       auto body = [&](auto mask_tag) {
@@ -398,15 +388,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
           zero16(dp);
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(frag_rows<QT>(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
-            dp = mfma32(frag_rows<QT>(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
+            s = mfma32(frag_rows(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
+            dp = mfma32(frag_rows(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
           }
           bf16x8_t pf[2], dsf[2];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             // this lane's query rows for registers 4g..4g+3 are consecutive: one 16-byte read per statistic
             const int ql0 = qb * 32 + 8 * g + 4 * hi;
-            const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0);
+            const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0) * LOG2E;
             const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
             int ds4[4] = {0, 0, 0, 0};
             if (MASK && HAS_DOC) {
@@ -433,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
             const int rbase = qb * 32 + s2 * 16 + 4 * hi;
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-              dv[db] = mfma32(frag_cols<QT>(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
-              dk[db] = mfma32(frag_cols<QT>(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
+              dv[db] = mfma32(frag_cols(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
+              dk[db] = mfma32(frag_cols(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
             }
           }
         }
@@ -444,11 +434,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
       if (need_mask) body(std::true_type{});
       else body(std::false_type{});
     }
-    __syncthreads();
-    if (jq + 1 < jq_hi) {
-      s_store((jq + 1) * QT);
-      __syncthreads();
-    }
+    attn_wait_vm<0>();
+    attn_barrier();
   }
 
   if (kvalid) {
@@ -463,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
         st_bf16x4(dvp + d0, ov);
-        // inverse rotation of the two (even, odd) pairs of dK
+        // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
         const float c0 = rcos[kvrow * 32 + d0 / 2], c1 = rcos[kvrow * 32 + d0 / 2 + 1];
         const float s0 = rsin[kvrow * 32 + d0 / 2], s1 = rsin[kvrow * 32 + d0 / 2 + 1];
         const float a0 = dk[db][4 * g + 0], b0 = dk[db][4 * g + 1], a1 = dk[db][4 * g + 2], b1 = dk[db][4 * g + 3];
@@ -479,24 +466,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 }
 
 // =============================================================================================
-// backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows)
+// backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows; q, k rotated)
 // =============================================================================================
 template <bool HAS_DOC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                          const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv, int T,
-                                                          int nh) {
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                             const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv, int T,
+                                                             int nh) {
   constexpr int KT = 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * (KT * 32 + 128)];
-  char* sK = smem;
-  char* sV = smem + 4 * (KT * 32 + 128);
+  constexpr int TILE = KT * 128;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE];  // [stage][K|V]
 
   const int nqt = gridDim.x;
   const int qt = nqt - 1 - blockIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   const int dm = nh * HD, ld = 3 * dm;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
   const int q0 = qt * 128, qw0 = q0 + wave * 32, qrow = qw0 + l31;
   const bool qvalid = qrow < T;
   const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
@@ -506,14 +494,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int d0 = ks * 16 + hi * 8;
-    qf[ks] = zero_bf16x8();
-    dof[ks] = zero_bf16x8();
-    if (qvalid) {
-      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + qrow * 32 + d0 / 2);
-      const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + qrow * 32 + d0 / 2);
-      qf[ks] = rope8(ld_bf16x8(base + (int64_t)qrow * ld + d0), cs, sn, 1.f);
-      dof[ks] = ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + d0);
-    }
+    qf[ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + d0) : zero_bf16x8();
+    dof[ks] = qvalid ? ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + d0) : zero_bf16x8();
   }
   float Lq = 0.f, Dq = 0.f;
   int dsq = 0;
@@ -522,55 +504,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     Dq = delta[((int64_t)b * nh + h) * T + qrow];
     if (HAS_DOC) dsq = doc_start[(int64_t)b * T + qrow];
   }
+  const int kv_hi = min(T, q0 + 128);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  int jt_lo = 0;
+  if (HAS_DOC) jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
+  asm volatile("; q/dO fragments resident" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(dof[0]), "v"(dof[1]), "v"(dof[2]),
+               "v"(dof[3]), "v"(Lq), "v"(Dq), "v"(dsq));
+
   f32x16_t dq[2];
   zero16(dq[0]);
   zero16(dq[1]);
 
-  int srow[2], schunk[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) stage_map(i * 256 + t, srow[i], schunk[i]);
-
-  const int kv_hi = min(T, q0 + 128);
-  const int jt_hi = (kv_hi + KT - 1) / KT;
-  int jt_lo = 0;
-  if (HAS_DOC) jt_lo = doc_start[(int64_t)b * T + q0] / KT;
-
-  bf16x8_t rk[2], rv[2];
-  f32x4_t rc[2], rs[2];
-  auto g_load = [&](int kv0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kv = kv0 + srow[i];
-      rk[i] = zero_bf16x8();
-      rv[i] = zero_bf16x8();
-      rc[i] = f32x4_t{1.f, 1.f, 1.f, 1.f};
-      rs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (kv < T) {
-        const uint16_t* p = base + (int64_t)kv * ld + schunk[i] * 8;
-        rk[i] = ld_bf16x8(p + dm);
-        rv[i] = ld_bf16x8(p + 2 * dm);
-        rc[i] = *reinterpret_cast<const f32x4_t*>(rcos + kv * 32 + schunk[i] * 4);
-        rs[i] = *reinterpret_cast<const f32x4_t*>(rsin + kv * 32 + schunk[i] * 4);
-      }
-    }
-  };
-  auto s_store = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = tile_off<KT>(srow[i], schunk[i] * 8);
-      *reinterpret_cast<bf16x8_t*>(sK + off) = rope8(rk[i], rc[i], rs[i], 1.f);
-      *reinterpret_cast<bf16x8_t*>(sV + off) = rv[i];
-    }
-  };
-
-  if (jt_lo < jt_hi) {
-    g_load(jt_lo * KT);
-    s_store();
-  }
-  __syncthreads();
-  for (int jt = jt_lo; jt < jt_hi; ++jt) {
+  TileDma dma;
+  dma.init(wave, lane);
+  auto stage = [&](int st, int jt) {
     const int kv0 = jt * KT;
-    if (jt + 1 < jt_hi) g_load((jt + 1) * KT);
+    const uint16_t* src = base + (int64_t)kv0 * ld;
+    dma.issue(smem + st * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+    dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+  };
+
+  if (jt_lo < jt_hi) stage(0, jt_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  int st = 0;
+  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) {
+    const int kv0 = jt * KT;
+    if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
+    const char* sK = smem + st * 2 * TILE;
+    const char* sV = sK + TILE;
     const bool wave_active = kv0 <= qw0 + 31;
     if (wave_active) {
       auto body = [&](auto mask_tag) {
@@ -582,8 +544,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
           zero16(dp);
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(frag_rows<KT>(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
-            dp = mfma32(frag_rows<KT>(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
+            s = mfma32(frag_rows(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
+            dp = mfma32(frag_rows(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
           }
           bf16x8_t dsf[2];
 #pragma unroll
@@ -601,18 +563,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
           for (int s2 = 0; s2 < 2; ++s2) {
             const int rbase = kb * 32 + s2 * 16 + 4 * hi;
 #pragma unroll
-            for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols<KT>(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
+            for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
           }
         }
       };
       if (HAS_DOC || (kv0 + KT - 1 > qw0)) body(std::true_type{});
       else body(std::false_type{});
     }
-    __syncthreads();
-    if (jt + 1 < jt_hi) {
-      s_store();
-      __syncthreads();
-    }
+    attn_wait_vm<0>();
+    attn_barrier();
   }
 
   if (qvalid) {
@@ -643,19 +602,32 @@ static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, 
   PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
   PLM_REQUIRE(B > 0 && T > 0 && nh > 0 && B < 65536 && nh < 65536 && T < (1 << 24), "%s: bad shape B=%ld T=%ld nh=%ld", name, (long)B,
               (long)T, (long)nh);
+  PLM_REQUIRE(T % 4 == 0, "%s: T=%ld must be a multiple of 4", name, (long)T);
   return PLM_OK;
 }
 
-extern "C" int plm_attn_fwd(const uint16_t* qkv, const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
-                            uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream) {
-  PLM_REQUIRE(qkv && rope_cos && rope_sin && out && lse, "plm_attn_fwd: null pointer");
+extern "C" int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
+                           void* stream) {
+  PLM_REQUIRE(qkv && rope_cos && rope_sin, "plm_rope_qk: null pointer");
+  if (int rc = check_attn_shape("plm_rope_qk", B, T, nh, hd)) return rc;
+  const int64_t items = B * T * (2 * nh * hd / 8);
+  int64_t blocks = plm_cdiv(items, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, qkv, rope_cos, rope_sin, B * T, (int)T, (int)nh);
+  PLM_CHECK_LAUNCH("plm_rope_qk");
+  return PLM_OK;
+}
+
+extern "C" int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,
+                            int64_t hd, void* stream) {
+  PLM_REQUIRE(qkv && out && lse, "plm_attn_fwd: null pointer");
   if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
   const dim3 grid((unsigned)plm_cdiv(T, 128), (unsigned)nh, (unsigned)B), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (doc_start)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, qkv, rope_cos, rope_sin, doc_start, out, lse, (int)T, (int)nh);
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, qkv, rope_cos, rope_sin, doc_start, out, lse, (int)T, (int)nh);
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
   PLM_CHECK_LAUNCH("plm_attn_fwd");
   return PLM_OK;
 }

@@ -166,7 +166,10 @@ class AttnFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, qkv, cos, sin, doc_start, B, T, nh):
-    out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh, doc_start)
+    # q, k are rotated in place in the projection output (this Function is its only consumer); the rotated
+    # buffer is what backward re-reads, and attn_bwd returns the gradient w.r.t. the un-rotated projection.
+    ops.rope_qk_(qkv, cos, sin, B, T, nh)
+    out, lse = ops.attn_fwd(qkv, B, T, nh, doc_start)
     ctx.save_for_backward(qkv, out, lse, cos, sin)
     ctx.doc_start = doc_start
     ctx.dims = (B, T, nh)

@@ -217,20 +217,28 @@ def gemm_tn(A, B, out=None, accumulate=False, alpha=None):
 
 
 # ---- attention ----------------------------------------------------------------------
-def attn_fwd(qkv, rope_cos, rope_sin, B, T, nh, doc_start=None):
-  _need(qkv, BF16, 'attn_fwd.qkv', 2)
+def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
+  """Rotate the q and k column blocks of the projection output in place (once per layer)."""
+  _need(qkv, BF16, 'rope_qk.qkv', 2)
   hd = qkv.shape[1] // (3 * nh)
-  _need(rope_cos, F32, 'attn_fwd.rope_cos', 2)
-  _need(rope_sin, F32, 'attn_fwd.rope_sin', 2)
+  _need(rope_cos, F32, 'rope_qk.rope_cos', 2)
+  _need(rope_sin, F32, 'rope_qk.rope_sin', 2)
   if rope_cos.shape[0] < T or rope_cos.shape[1] != hd // 2:
-    raise ValueError('attn_fwd: RoPE table too short for T or wrong head_dim')
+    raise ValueError('rope_qk: RoPE table too short for T or wrong head_dim')
+  _lib.check(_lib.load().plm_rope_qk(_p(qkv), _p(rope_cos), _p(rope_sin), B, T, nh, hd, _stream()), 'plm_rope_qk')
+  return qkv
+
+
+def attn_fwd(qkv_rot, B, T, nh, doc_start=None):
+  """qkv_rot: projection output with q, k already rotated (rope_qk_)."""
+  _need(qkv_rot, BF16, 'attn_fwd.qkv', 2)
+  hd = qkv_rot.shape[1] // (3 * nh)
   if doc_start is not None:
     _need(doc_start, torch.int32, 'attn_fwd.doc_start', 2)
-  out = torch.empty((B * T, nh * hd), dtype=BF16, device=qkv.device)
-  lse = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
+  out = torch.empty((B * T, nh * hd), dtype=BF16, device=qkv_rot.device)
+  lse = torch.empty((B, nh, T), dtype=F32, device=qkv_rot.device)
   with _Timed('attn_fwd', 4.0 * B * nh * hd * T * (T + 1) / 2):
-    _lib.check(_lib.load().plm_attn_fwd(_p(qkv), _p(rope_cos), _p(rope_sin), _p(doc_start), _p(out), _p(lse), B, T, nh, hd,
-                                        _stream()), 'plm_attn_fwd')
+    _lib.check(_lib.load().plm_attn_fwd(_p(qkv_rot), _p(doc_start), _p(out), _p(lse), B, T, nh, hd, _stream()), 'plm_attn_fwd')
   return out, lse
 
 

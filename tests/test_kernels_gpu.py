@@ -272,14 +272,30 @@ def test_attention_fwd_bwd(ops, B, T, nh, masked):
   ref.backward(dout.float())
   cos, sin = (t.cuda() for t in O.rope_table(64, T))
   dsg = None if ds is None else ds.cuda()
-  out, lse = ops.attn_fwd(qkv.cuda(), cos, sin, B, T, nh, dsg)
+  qrot = ops.rope_qk_(qkv.cuda(), cos, sin, B, T, nh)
+  out, lse = ops.attn_fwd(qrot, B, T, nh, dsg)
   close(out.float(), ref, 1.6e-2, 'attention out')
-  dqkv = ops.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, cos, sin, B, T, nh, dsg)
+  dqkv = ops.attn_bwd(qrot, out, dout.cuda(), lse, cos, sin, B, T, nh, dsg)
   gq, gk, gv = (t for t in leaf.grad.split(d, dim=1))
   dq, dk, dv = (t.float() for t in dqkv.split(d, dim=1))
   close(dv, gv, 2e-2, 'attention dV')
   close(dk, gk, 2e-2, 'attention dK')
   close(dq, gq, 2e-2, 'attention dQ')
+
+
+def test_rope_qk_golden(ops, golden_dir):
+  """In-place RoPE against the reference's apply_rotary_emb_complex_like outputs."""
+  z = {k: torch.from_numpy(v) for k, v in np.load(f'{golden_dir}/ops.npz').items() if k.startswith('rope_')}
+  B, T, nh, hd = z['rope_q'].shape
+  d = nh * hd
+  qkv = bf(torch.cat([z['rope_q'].reshape(B * T, d), z['rope_k'].reshape(B * T, d), torch.ones(B * T, d)], dim=1)).cuda()
+  cos, sin = (t.cuda() for t in O.rope_table(hd, T))
+  ref_q = O.rope_apply(qkv[:, :d].float().cpu().reshape(B, T, nh, hd), cos.cpu(), sin.cpu()).reshape(B * T, d)
+  ops.rope_qk_(qkv, cos, sin, B, T, nh)
+  close(qkv[:, :d].float(), z['rope_qr'].reshape(B * T, d), 8e-3, 'rope q vs reference')
+  close(qkv[:, d:2 * d].float(), z['rope_kr'].reshape(B * T, d), 8e-3, 'rope k vs reference')
+  assert (qkv[:, :d].float().cpu() - ref_q).abs().max() <= 2 ** -7 * ref_q.abs().max()
+  assert (qkv[:, 2 * d:] == 1).all()  # v untouched
 
 
 def test_attention_softmax_rescale_branch(ops):
@@ -292,7 +308,7 @@ def test_attention_softmax_rescale_branch(ops):
   qkv = bf(qkv)
   ref = _attn_ref(qkv, B, T, nh, None)
   cos, sin = (t.cuda() for t in O.rope_table(64, T))
-  out, _ = ops.attn_fwd(qkv.cuda(), cos, sin, B, T, nh)
+  out, _ = ops.attn_fwd(ops.rope_qk_(qkv.cuda(), cos, sin, B, T, nh), B, T, nh)
   close(out.float(), ref, 1.6e-2, 'attention with max jump')
 
 
@@ -308,7 +324,7 @@ def test_attention_golden(ops, golden_dir):
     if tag == 'm':
       docs = [[int(v) for v in row if v > 0] for row in z['attm_docs_lengths']]
       ds = O.doc_start_from_lengths(docs, T).cuda()
-    out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh, ds)
+    out, lse = ops.attn_fwd(qkv, B, T, nh, ds)  # identity RoPE: the golden SDPA vectors have none
     close(out.float(), z[f'att{tag}_o'].reshape(B * T, nh * hd), 2e-2, f'attention golden {tag}')
     dqkv = ops.attn_bwd(qkv, out, bf(z[f'att{tag}_do']).reshape(B * T, nh * hd).cuda(), lse, cos, sin, B, T, nh, ds)
     for i, n in enumerate('qkv'):

@@ -86,9 +86,11 @@ def main():
     cos, sin = (t.to(dev) for t in O.rope_table(64, T))
     qkv = torch.randn(M, 3 * d, device=dev).to(BF)
     dout = torch.randn(M, d, device=dev).to(BF)
-    out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh)
+    ops.rope_qk_(qkv, cos, sin, B, T, nh)
+    out, lse = ops.attn_fwd(qkv, B, T, nh)
     fl = 2.0 * 2 * B * nh * T * (T + 1) / 2 * 64  # causal-counted QK^T + PV
-    rec('attn fwd', timeit(lambda: ops.attn_fwd(qkv, cos, sin, B, T, nh), a.iters), flops=fl)
+    rec('rope qk (in place)', timeit(lambda: ops.rope_qk_(qkv, cos, sin, B, T, nh), a.iters), bytes_=8.0 * M * d)
+    rec('attn fwd', timeit(lambda: ops.attn_fwd(qkv, B, T, nh), a.iters), flops=fl)
     rec('attn bwd', timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh), a.iters), flops=2.0 * fl)
 
   if want('hbm'):

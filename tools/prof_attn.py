@@ -8,6 +8,6 @@ cos, sin = (t.cuda() for t in O.rope_table(64, T))
 qkv = torch.randn(B * T, 3 * d, device='cuda').to(torch.bfloat16)
 dout = torch.randn(B * T, d, device='cuda').to(torch.bfloat16)
 for _ in range(3):
-  out, lse = ops.attn_fwd(qkv, cos, sin, B, T, nh)
+  out, lse = ops.attn_fwd(qkv, B, T, nh)
   ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh)
 torch.cuda.synchronize()
