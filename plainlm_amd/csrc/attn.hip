@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv
 // forward (q, k already rotated)
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
   constexpr int KT = 64;            // kv rows per tile
   constexpr int TILE = KT * 128;    // 8 KiB
@@ -181,17 +181,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
   };
 
-  if (jt_lo < jt_hi) stage(0, jt_lo);
-  attn_wait_vm<0>();
-  attn_barrier();
-  int st = 0;
-  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) {
+  // one KV tile: S^T = K Q^T, online softmax (masked or not), O^T += V^T P^T
+  auto tile_body = [&](int jt, int st, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int kv0 = jt * KT;
     if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
     const char* sK = smem + st * 2 * TILE;
     const char* sV = sK + TILE;
-    const bool wave_active = kv0 <= qw0 + 31;  // tile not entirely above this wave's diagonal
-    if (wave_active) {
+    if (kv0 <= qw0 + 31) {  // tile not entirely above this wave's diagonal
       f32x16_t s[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -199,62 +196,66 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows(sK, kb * 32 + l31, ks, hi), qf[ks], s[kb]);
       }
-      // masking is only needed on tiles that touch the diagonal (or always with document masks)
-      auto softmax_pv = [&](auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
-        float tmax = -INFINITY;
+      float tmax = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (MASK) {
-              const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
-              const bool ok = (kvg <= qrow) && (!HAS_DOC || kvg >= dsq);
-              if (!ok) s[kb][r] = -INFINITY;
-            }
-            tmax = fmaxf(tmax, s[kb][r]);
+        for (int r = 0; r < 16; ++r) {
+          if (MASK) {
+            const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+            const bool ok = (kvg <= qrow) && (!HAS_DOC || kvg >= dsq);
+            if (!ok) s[kb][r] = -INFINITY;
           }
+          tmax = fmaxf(tmax, s[kb][r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = fast_exp2((m - m_safe) * c2);
-        const float mc = m_safe * c2;
-        float psum = 0.f;
-        bf16x8_t pf[4];
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2((m - m_safe) * c2);
+      const float mc = m_safe * c2;
+      float psum = 0.f;
+      bf16x8_t pf[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = fast_exp2(s[kb][r] * c2 - mc);
-            psum += p;
-            pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(s[kb][r] * c2 - mc);
+          psum += p;
+          pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
         }
-        lsum = lsum * alpha + psum;
-        const bool grew = m_new > m;
-        m = m_new;
-        if (__builtin_amdgcn_ballot_w64(grew) != 0ull) {  // wave-uniform: skip the O rescale when no row max moved
+      }
+      lsum = lsum * alpha + psum;
+      const bool grew = m_new > m;
+      m = m_new;
+      if (__builtin_amdgcn_ballot_w64(grew) != 0ull) {  // wave-uniform: skip the O rescale when no row max moved
 #pragma unroll
-          for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          const int rbase = (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi;
+          o[db] = mfma32(frag_cols(sV, db, rbase, lane), pf[sp], o[db]);
         }
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-#pragma unroll
-          for (int sp = 0; sp < 4; ++sp) {
-            const int rbase = (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi;
-            o[db] = mfma32(frag_cols(sV, db, rbase, lane), pf[sp], o[db]);
-          }
-        }
-      };
-      if (HAS_DOC || (kv0 + KT - 1 > qw0)) softmax_pv(std::true_type{});
-      else softmax_pv(std::false_type{});
+      }
     }
     attn_wait_vm<0>();  // next tile landed (this wave's pieces) ...
     attn_barrier();     // ... everyone's; and every wave is done reading the current stage
-  }
+  };
+
+  if (jt_lo < jt_hi) stage(0, jt_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  // Tiles strictly below the block's first query row need no mask (pure causal): run them in their own loop so the
+  // mask code does not inflate the register allocation of the hot loop; the last tiles touch the diagonal.
+  const int jt_diag = HAS_DOC ? jt_lo : max(jt_lo, min(jt_hi, q0 / KT));
+  int st = 0;
+  for (int jt = jt_lo; jt < jt_diag; ++jt, st ^= 1) tile_body(jt, st, std::false_type{});
+  for (int jt = jt_diag; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st, std::true_type{});
 
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   if (qvalid) {
@@ -365,11 +366,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
     }
   };
 
-  if (jq_lo < jq_hi) stage(0, jq_lo);
-  attn_wait_vm<0>();
-  attn_barrier();
-  int st = 0;
-  for (int jq = jq_lo; jq < jq_hi; ++jq, st ^= 1) {
+  auto tile_body = [&](int jq, int st, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int qt0 = jq * QT;
     if (jq + 1 < jq_hi) stage(st ^ 1, jq + 1);
     const char* sQ = smem + st * STAGE;
@@ -377,66 +375,70 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
     const float* sL = reinterpret_cast<const float*>(sQ + 2 * TILE);
     const float* sD = sL + 64;
     const int* sDS = reinterpret_cast<const int*>(sL + 128);
-    const bool wave_active = qt0 + QT - 1 >= kvw0;  // some query at or below this wave's first key
-    if (wave_active) {
-      auto body = [&](auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
+    if (qt0 + QT - 1 >= kvw0) {  // some query at or below this wave's first key
 #pragma unroll 1
-        for (int qb = 0; qb < 2; ++qb) {
-          f32x16_t s, dp;
-          zero16(s);
-          zero16(dp);
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16_t s, dp;
+        zero16(s);
+        zero16(dp);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(frag_rows(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
-            dp = mfma32(frag_rows(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
-          }
-          bf16x8_t pf[2], dsf[2];
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma32(frag_rows(sQ, qb * 32 + l31, ks, hi), kf[ks], s);       // S[q][kv]
+          dp = mfma32(frag_rows(sDO, qb * 32 + l31, ks, hi), vf[ks], dp);    // dP[q][kv]
+        }
+        bf16x8_t pf[2], dsf[2];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            // this lane's query rows for registers 4g..4g+3 are consecutive: one 16-byte read per statistic
-            const int ql0 = qb * 32 + 8 * g + 4 * hi;
-            const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0) * LOG2E;
-            const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
-            int ds4[4] = {0, 0, 0, 0};
-            if (MASK && HAS_DOC) {
+        for (int g = 0; g < 4; ++g) {
+          // this lane's query rows for registers 4g..4g+3 are consecutive: one 16-byte read per statistic
+          const int ql0 = qb * 32 + 8 * g + 4 * hi;
+          const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0) * LOG2E;
+          const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
+          int ds4[4] = {0, 0, 0, 0};
+          if (MASK && HAS_DOC) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) ds4[e] = sDS[ql0 + e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * g + e;
-              float p = fast_exp2(s[r] * c2 - L4[e]);
-              if (MASK) {
-                const int qg = qt0 + ql0 + e;
-                bool ok = (kvrow <= qg) && (qg < T);
-                if (HAS_DOC) ok = ok && (kvrow >= ds4[e]);
-                p = ok ? p : 0.f;
-              }
-              const float dsv = p * (dp[r] - D4[e]) * scale;
-              pf[r >> 3][r & 7] = f2bf(p);
-              dsf[r >> 3][r & 7] = f2bf(dsv);
-            }
+            for (int e = 0; e < 4; ++e) ds4[e] = sDS[ql0 + e];
           }
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int rbase = qb * 32 + s2 * 16 + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-              dv[db] = mfma32(frag_cols(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
-              dk[db] = mfma32(frag_cols(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float p = fast_exp2(s[r] * c2 - L4[e]);
+            if (MASK) {
+              const int qg = qt0 + ql0 + e;
+              bool ok = (kvrow <= qg) && (qg < T);
+              if (HAS_DOC) ok = ok && (kvrow >= ds4[e]);
+              p = ok ? p : 0.f;
             }
+            const float dsv = p * (dp[r] - D4[e]) * scale;
+            pf[r >> 3][r & 7] = f2bf(p);
+            dsf[r >> 3][r & 7] = f2bf(dsv);
           }
         }
-      };
-      // unmasked fast path: every query of the tile is at/after every key of this wave and inside T
-      const bool need_mask = HAS_DOC || (qt0 < kvw0 + 31) || (qt0 + QT > T);
-      if (need_mask) body(std::true_type{});
-      else body(std::false_type{});
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int rbase = qb * 32 + s2 * 16 + 4 * hi;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = mfma32(frag_cols(sDO, db, rbase, lane), pf[s2], dv[db]);   // dV^T[d][kv]
+            dk[db] = mfma32(frag_cols(sQ, db, rbase, lane), dsf[s2], dk[db]);   // dK^T[d][kv]
+          }
+        }
+      }
     }
     attn_wait_vm<0>();
     attn_barrier();
-  }
+  };
+
+  if (jq_lo < jq_hi) stage(0, jq_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  // three segments so the mask code stays out of the hot loop: the two tiles on the diagonal of this key block,
+  // the tiles entirely below it (pure causal: unmasked), and a last partial tile when T % 64 != 0
+  const int jq_d = min(jq_hi, jq_lo + 2);
+  const int jq_u = HAS_DOC ? jq_d : max(jq_d, min(jq_hi, T / QT));
+  int st = 0, jq = jq_lo;
+  for (; jq < jq_d; ++jq, st ^= 1) tile_body(jq, st, std::true_type{});
+  for (; jq < jq_u; ++jq, st ^= 1) tile_body(jq, st, std::false_type{});
+  for (; jq < jq_hi; ++jq, st ^= 1) tile_body(jq, st, std::true_type{});
 
   if (kvalid) {
     uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 // backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows; q, k rotated)
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                              const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv, int T,
@@ -524,55 +526,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
   };
 
-  if (jt_lo < jt_hi) stage(0, jt_lo);
-  attn_wait_vm<0>();
-  attn_barrier();
-  int st = 0;
-  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) {
+  auto tile_body = [&](int jt, int st, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int kv0 = jt * KT;
     if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
     const char* sK = smem + st * 2 * TILE;
     const char* sV = sK + TILE;
-    const bool wave_active = kv0 <= qw0 + 31;
-    if (wave_active) {
-      auto body = [&](auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
+    if (kv0 <= qw0 + 31) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          f32x16_t s, dp;
-          zero16(s);
-          zero16(dp);
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16_t s, dp;
+        zero16(s);
+        zero16(dp);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(frag_rows(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
-            dp = mfma32(frag_rows(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
-          }
-          bf16x8_t dsf[2];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float p = fast_exp2(s[r] * c2 - Lq);
-            if (MASK) {
-              const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
-              bool ok = (kvg <= qrow);
-              if (HAS_DOC) ok = ok && (kvg >= dsq);
-              p = ok ? p : 0.f;
-            }
-            dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq) * scale);
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int rbase = kb * 32 + s2 * 16 + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
-          }
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma32(frag_rows(sK, kb * 32 + l31, ks, hi), qf[ks], s);      // S^T[kv][q]
+          dp = mfma32(frag_rows(sV, kb * 32 + l31, ks, hi), dof[ks], dp);   // dP^T[kv][q]
         }
-      };
-      if (HAS_DOC || (kv0 + KT - 1 > qw0)) body(std::true_type{});
-      else body(std::false_type{});
+        bf16x8_t dsf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(s[r] * c2 - Lq);
+          if (MASK) {
+            const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+            bool ok = (kvg <= qrow);
+            if (HAS_DOC) ok = ok && (kvg >= dsq);
+            p = ok ? p : 0.f;
+          }
+          dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq) * scale);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int rbase = kb * 32 + s2 * 16 + 4 * hi;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_cols(sK, db, rbase, lane), dsf[s2], dq[db]);  // dQ^T[d][q]
+        }
+      }
     }
     attn_wait_vm<0>();
     attn_barrier();
-  }
+  };
+
+  if (jt_lo < jt_hi) stage(0, jt_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  const int jt_diag = HAS_DOC ? jt_lo : max(jt_lo, min(jt_hi, q0 / KT));  // tiles below q0 need no mask
+  int st = 0;
+  for (int jt = jt_lo; jt < jt_diag; ++jt, st ^= 1) tile_body(jt, st, std::false_type{});
+  for (int jt = jt_diag; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st, std::true_type{});
 
   if (qvalid) {
     uint16_t* dqp = dqkv + ((int64_t)b * T + qrow) * ld + h * HD;

@@ -607,28 +607,34 @@ static int tn_splits(int64_t M, int64_t N, int64_t K) {
   return (int)(s < 1 ? 1 : s);
 }
 
-int plm_tn_big_splits(int64_t M, int64_t N, int64_t K);  // gemm_big.hip (0 = big-tile kernel not applicable)
-void plm_launch_gemm_tn_big(int mode, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C,
-                            int64_t ldc, int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s);
+bool plm_tn_big_plan(int64_t M, int64_t N, int64_t K, int* splits, int* rfull);  // gemm_big.hip
+void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                            float* C, int64_t ldc, float* slabs, int64_t M, int64_t N, int64_t K, const float* alpha_dev,
+                            hipStream_t s);
 
-// one place decides kernel + split count, so the workspace query and the launch always agree
-static int tn_plan(int64_t M, int64_t N, int64_t K, bool& big) {
+// one place decides kernel + split layout, so the workspace query and the launch always agree.
+// rfull: tile rows (of 256) that the big kernel computes without split (0 for the 128x128 kernels).
+static int tn_plan(int64_t M, int64_t N, int64_t K, bool& big, int& rfull) {
   big = false;
+  rfull = 0;
   if (getenv("PLM_TN_NO_BIG") == nullptr && getenv("PLM_GEMM_V1") == nullptr) {
-    const int sb = plm_tn_big_splits(M, N, K);
-    if (sb > 0) {
+    int sb = 1;
+    if (plm_tn_big_plan(M, N, K, &sb, &rfull)) {
       big = true;
       return sb;
     }
   }
+  rfull = 0;
   return tn_splits(M, N, K);
 }
 
 extern "C" size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   bool big;
-  const int s = tn_plan(M, N, K, big);
-  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+  int rfull;
+  const int s = tn_plan(M, N, K, big, rfull);
+  const int64_t rows = M - (int64_t)rfull * 256;
+  return (s > 1 && rows > 0) ? (size_t)s * (size_t)rows * (size_t)N * sizeof(float) : 0;
 }
 
 extern "C" int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -644,24 +650,29 @@ extern "C" int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* 
               "plm_gemm_bf16_tn: base pointers must be 16-byte aligned");
   const int tiles_m = (int)plm_cdiv(M, GBM), tiles_n = (int)plm_cdiv(N, GBN);
   bool big;
-  const int splits = tn_plan(M, N, K, big);
+  int rfull;
+  const int splits = tn_plan(M, N, K, big, rfull);
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(256);
   if (big) {
-    if (splits == 1) {
-      plm_launch_gemm_tn_big(accumulate ? 1 : 0, 1, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
-    } else {
-      const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+    const int64_t rem_rows = M - (int64_t)rfull * 256;  // rows whose tiles are split over K
+    const bool split_part = splits > 1 && rem_rows > 0;
+    if (split_part) {
+      const size_t need = (size_t)splits * (size_t)rem_rows * (size_t)N * sizeof(float);
       if (!workspace || workspace_bytes < need) {
         plm_set_error("plm_gemm_bf16_tn: workspace of %zu bytes required, %zu given", need, workspace_bytes);
         return PLM_E_WORKSPACE;
       }
-      plm_launch_gemm_tn_big(2, splits, A, lda, B, ldb, (float*)workspace, (int64_t)N, M, N, K, nullptr, s);
-      const int64_t nv = M * (N / 4);
+      PLM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "plm_gemm_bf16_tn: workspace must be 16-byte aligned");
+    }
+    plm_launch_gemm_tn_big(split_part ? splits : 1, split_part ? rfull : (int)plm_cdiv(M, 256), accumulate, A, lda, B, ldb, C, ldc,
+                           (float*)workspace, M, N, K, alpha_dev, s);
+    if (split_part) {
+      const int64_t nv = rem_rows * (N / 4);
       int64_t rb = plm_cdiv(nv, 256);
       if (rb > 4096) rb = 4096;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), block, 0, s, (const float*)workspace, C, ldc, (int)M, (int)N, splits,
-                         accumulate, alpha_dev);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), block, 0, s, (const float*)workspace, C + (int64_t)rfull * 256 * ldc, ldc,
+                         (int)rem_rows, (int)N, splits, accumulate, alpha_dev);
     }
     PLM_CHECK_LAUNCH("plm_gemm_bf16_tn (big tile)");
     return PLM_OK;

@@ -287,10 +287,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 // the 32-byte column pairs of row k are rotated by 2*(k&3) on the DMA source address so that the
 // ds_read_b64_tr_b16 operand reads (k = token row) are bank-conflict free (see gemm_tn_dma_kernel).
 // =============================================================================================
-template <int MODE>  // 0: C = alpha*acc   1: C += alpha*acc   2: raw partial into slab[split] (ld = N)
+// Work items: the first n_full tiles (tile rows 0 .. rfull-1) take the whole contraction and write C directly
+// (C = / += alpha*acc); the tiles of the remaining rows are split `splits` ways over K and write raw fp32 partials
+// into slab[split][row - rfull*256][N], summed by splitk_reduce_kernel.  rfull = 0 is plain split-K (small
+// outputs), splits = 1 with no remainder is plain tiling; the hybrid keeps every CU busy for a whole number of rounds.
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                             int64_t ldc, int M, int N, int K, int kchunk, int splits,
+                                                             int64_t ldc, float* __restrict__ slabs, int M, int N, int K, int kchunk,
+                                                             int splits, int rfull, int accumulate,
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
   constexpr int BM = 256, BN = 256, WN = 4;
   constexpr int TM = 128, TN = 64, AH = 64, AF = 2;
@@ -304,16 +308,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
-  const int ntiles = tiles_m * tiles_n;
-  const int nitems = ntiles * splits;
+  const int n_full = rfull * tiles_n;
+  const int n_rem = tiles_m * tiles_n - n_full;
+  const int nitems = n_full + n_rem * splits;
 
+  // split = -1: whole-K tile written to C; split >= 0: partial into slab[split]
   auto coords = [&](int item, int& i0, int& j0, int& kbeg, int& kend, int& split) {
-    split = item / ntiles;
-    const int tile = item - split * ntiles;
+    int tile;
+    if (item < n_full) {
+      split = -1;
+      tile = item;
+      kbeg = 0;
+      kend = K;
+    } else {
+      const int j = item - n_full;
+      split = j / n_rem;
+      tile = n_full + (j - split * n_rem);
+      kbeg = min(K, split * kchunk);
+      kend = min(K, kbeg + kchunk);
+    }
     i0 = (tile / tiles_n) * BM;
     j0 = (tile % tiles_n) * BN;
-    kbeg = min(K, split * kchunk);
-    kend = min(K, kbeg + kchunk);
   };
 
   // DMA lane map: instruction q = i*8 + wave covers k-rows q*4 .. q*4+3; lane -> (row, physical 16-byte chunk)
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 
   const int first = xcd_remap(blockIdx.x, gridDim.x);
   if (first >= nitems) return;
-  float alpha = (MODE != 2 && alpha_dev) ? *alpha_dev : 1.f;
+  float alpha = alpha_dev ? *alpha_dev : 1.f;
   asm volatile("; alpha pinned" : "+v"(alpha));
 
   // staging cursor: (s_item, s_k) = next K-tile to stage; s_kend = end of that item's K range
@@ -455,8 +470,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     }
 
     // epilogue: D[i][j], lane owns column j = l31, 16 rows per accumulator; 128-byte row segments per half-wave
-    float* out = (MODE == 2) ? C + (int64_t)split * M * N : C;
-    const int64_t ld = (MODE == 2) ? N : ldc;
+    const bool direct = split < 0;  // workgroup-uniform
+    const int mrem = M - rfull * BM;
+    float* out = direct ? C : slabs + ((int64_t)split * mrem - (int64_t)rfull * BM) * N;
+    const int64_t ld = direct ? ldc : N;
+    const float scl = direct ? alpha : 1.f;
+    const bool rmw = direct && accumulate;
 #pragma unroll
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int row0 = i0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
@@ -469,43 +488,49 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
           const int row = row0 + mfma32_row(r, hi);
           if (row >= M) continue;
           float* dst = out + (int64_t)row * ld + col;
-          const float v = acc[mf][bh][r] * alpha;
-          *dst = (MODE == 1) ? *dst + v : v;
+          const float v = acc[mf][bh][r] * scl;
+          *dst = rmw ? *dst + v : v;
         }
       }
     }
   }
 }
 
-// chooses the split count for the big TN kernel; 0 = do not use it
-int plm_tn_big_splits(int64_t M, int64_t N, int64_t K) {
+// Plan for the big TN kernel: returns false when it should not be used.  rfull = tile rows done without split.
+bool plm_tn_big_plan(int64_t M, int64_t N, int64_t K, int* splits, int* rfull) {
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (K % 64 != 0 || M < 256 || N < 256) return 0;
-  const int64_t tiles = plm_cdiv(M, 256) * plm_cdiv(N, 256);
-  if (tiles >= g_num_cus) return round_efficiency(tiles, g_num_cus) >= 0.85 ? 1 : 0;
-  int64_t s = g_num_cus / tiles;
+  if (K % 64 != 0 || M < 256 || N < 256) return false;
+  const int64_t R = plm_cdiv(M, 256), Cn = plm_cdiv(N, 256), tiles = R * Cn;
   const int64_t max_by_k = K / 512 > 0 ? K / 512 : 1;  // >= 8 K-tiles per item
+  int64_t rf = 0, s = 1;
+  if (tiles < g_num_cus) {
+    s = g_num_cus / tiles;
+  } else {
+    rf = ((tiles / g_num_cus) * g_num_cus) / Cn;
+    const int64_t rem = (R - rf) * Cn;
+    s = rem > 0 ? g_num_cus / rem : 1;
+  }
   if (s > max_by_k) s = max_by_k;
-  return (int)(s < 1 ? 1 : s);
+  if (s < 1) s = 1;
+  *splits = (int)s;
+  *rfull = (int)rf;
+  return true;
 }
 
-void plm_launch_gemm_tn_big(int mode, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C,
-                            int64_t ldc, int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s) {
+void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                            float* C, int64_t ldc, float* slabs, int64_t M, int64_t N, int64_t K, const float* alpha_dev,
+                            hipStream_t s) {
   const int tm = (int)plm_cdiv(M, 256), tn = (int)plm_cdiv(N, 256);
   const int kchunk = (int)(plm_cdiv(plm_cdiv(K, splits), 64) * 64);
-  const int nitems = tm * tn * splits;
+  const int nitems = rfull * tn + (tm - rfull) * tn * splits;
   const dim3 grid(nitems < g_num_cus ? nitems : g_num_cus), block(512);
-#define PLM_TNB(MODE_) \
-  hipLaunchKernelGGL(gemm_tn_big_kernel<MODE_>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, splits, alpha_dev, tm, tn)
-  if (mode == 0) PLM_TNB(0);
-  else if (mode == 1) PLM_TNB(1);
-  else PLM_TNB(2);
-#undef PLM_TNB
+  hipLaunchKernelGGL(gemm_tn_big_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
+                     accumulate, alpha_dev, tm, tn);
 }
 
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.

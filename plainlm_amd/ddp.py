@@ -105,7 +105,7 @@ class GradReducer:
       reducer.finish()                           # after backward, before clip/optimizer
   """
 
-  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True):
+  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False):
     self.flat = flat_grad
     self.comm = comm
     self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)))
@@ -117,12 +117,13 @@ class GradReducer:
     self.on_gpu = flat_grad.is_cuda
     self.overlap = overlap and self.on_gpu
     self.stream = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
+    self.force = force  # run the collectives even with a single rank (tests the RCCL path on one GPU)
     self.sync = False
     self.pending = None
     self.launched = []
 
   def begin(self, sync):
-    self.sync = bool(sync) and self.comm.world_size > 1
+    self.sync = bool(sync) and (self.comm.world_size > 1 or self.force)
     self.pending = [len(idxs) for (_, _, idxs) in self.buckets]
     self.launched = []
 
@@ -163,7 +164,7 @@ class GradReducer:
 
   def broadcast_params(self, flat_params_or_list):
     """C1: rank-0 parameters to every rank once at wrap time."""
-    if self.comm.world_size == 1:
+    if self.comm.world_size == 1 and not self.force:
       return
     tensors = flat_params_or_list if isinstance(flat_params_or_list, (list, tuple)) else [flat_params_or_list]
     for t in tensors:

@@ -206,7 +206,7 @@ def test_gemm_nt_strided_operand(ops):
 
 
 TN_SHAPES = [(128, 128, 64), (256, 128, 512), (136, 72, 200), (2304, 768, 4096), (768, 2048, 1000), (50280, 768, 256),
-             (8, 8, 8), (768, 768, 32768), (520, 264, 192), (304, 1000, 1024), (4096, 768, 8192), (256, 256, 64)]
+             (8, 8, 8), (768, 768, 32768), (520, 264, 192), (304, 1000, 1024), (4096, 768, 8192), (256, 256, 64), (50280, 768, 2048), (66000, 256, 1024)]
 
 
 @pytest.mark.parametrize('M,N,K', TN_SHAPES)

@@ -235,3 +235,35 @@ def test_160m_loss_and_grad_parity_vs_oracle(P):
             'layers.5.attn_norm.weight', 'embed_tokens.weight'):
     g = dict(m.named_parameters())[n].grad
     assert relmax(g, og[n]) < 6e-2, (n, relmax(g, og[n]))
+
+
+def test_rccl_reducer_single_rank(P, mdl):
+  """The direct-RCCL data plane (plm_comm_* through the C ABI) on one GPU: communicator init, bucketed
+  all-reduce-mean on the side stream chained to backward by events, broadcast, stream join.  With one rank the
+  mean is the identity, so gradients must equal the un-reduced ones exactly and all buckets must have fired."""
+  from plainlm_amd import ddp
+  m = _small(P, mdl, main_grad=True)
+  tok = mdl['tokens']
+  ids, tgt = tok[:, :64].cuda(), tok[:, 1:65].cuda()
+  m.sink.begin_window()
+  m.loss(ids, tgt).backward()
+  torch.cuda.synchronize()
+  want = m._flat_grad.clone()
+  comm = ddp.RcclComm(0, 1, torch.cuda.current_device())
+  red = ddp.GradReducer(m._flat_grad, list(m.parameters()), m._grad_spans, comm, bucket_cap_mb=0.25, force=True)
+  assert len(red.buckets) >= 4
+  red.broadcast_params([p.data for p in m.parameters()])
+  m.sink.on_ready = red.param_ready
+  fired = []
+  orig = comm.allreduce_avg_
+  comm.allreduce_avg_ = lambda span, stream: (fired.append(span.numel()), orig(span, stream))[1]
+  m.sink.begin_window()
+  red.begin(sync=True)
+  m.loss(ids, tgt).backward()
+  n_during_backward = len(fired)
+  red.finish()
+  torch.cuda.synchronize()
+  assert n_during_backward == len(red.buckets) == len(fired)  # every bucket launched from inside backward
+  assert sum(fired) == m._flat_grad.numel()
+  assert torch.equal(m._flat_grad, want)
+  comm.close()
