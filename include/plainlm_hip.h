@@ -105,6 +105,11 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  *               rotation is applied in the kernels' epilogues) and v; delta fp32[B,nh,T] scratch. */
 int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                 void* stream);
+/* w_qkv projection fused with RoPE (transformer.py:42-47): QKV[M, 3*nh*hd] = X[M,K] W[3*nh*hd, K]^T with the q | k
+ * blocks rotated in the GEMM epilogue (falls back to GEMM + plm_rope_qk for shapes the big-tile kernel declines). */
+int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* QKV, int64_t ldq, int64_t M,
+                      int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
+                      void* stream);
 int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,
                  int64_t hd, void* stream);
 int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,

@@ -40,6 +40,7 @@ SIGNATURES = {
   'plm_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
   'plm_gemm_bf16_tn': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
   'plm_rope_qk': (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+  'plm_qkv_rope_bf16': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P]),

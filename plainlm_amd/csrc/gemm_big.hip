@@ -52,11 +52,22 @@ static double round_efficiency(int64_t tiles, int slots) {
 // STAG: every phase is split into a READ section (DMA issue, ds_reads, counted vmcnt wait) and an MFMA section with a
 // barrier after each; the wave group wm-odd runs one barrier behind the other (waves w and w+4 share a SIMD and sit in
 // different groups), so one group's LDS reads overlap the other group's MFMAs; s_setprio(1) around the MFMA cluster.
-template <int BM, int BN, int WM, int WN, bool STAG>
+// ROPE: the epilogue applies the interleaved-pair rotary embedding (models/embeddings.py:15-30) to the output
+// columns [0, rope_cols) before the bf16 rounding: row m is token position m % rope_T, column n is head dim n % 64,
+// pair (n, n+1) rotates by the angle of rope tables [T][32].  Used for the w_qkv projection (q | k blocks).
+struct RopeArgs {
+  const float* cos_t;
+  const float* sin_t;
+  int T;
+  int cols;
+};
+
+template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
+                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
+                                                             RopeArgs rope) {
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   static_assert(WM * WN == 8 && TN == 64 && (TM == 128 || TM == 64), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
@@ -253,13 +264,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
+      const int tpos = ROPE ? (mrow0 + l31) % rope.T : 0;  // token position of this lane's row
 #pragma unroll
       for (int bh = 0; bh < 2; ++bh) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           bf16x4_t o;
+          if (ROPE) {
+            const int ncol = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns
+            float v0 = acc[mf][bh][4 * g + 0] * alpha, v1 = acc[mf][bh][4 * g + 1] * alpha;
+            float v2 = acc[mf][bh][4 * g + 2] * alpha, v3 = acc[mf][bh][4 * g + 3] * alpha;
+            if (ncol < rope.cols) {
+              const int pi = tpos * 32 + (ncol & 63) / 2;
+              const float c0 = rope.cos_t[pi], c1 = rope.cos_t[pi + 1], s0 = rope.sin_t[pi], s1 = rope.sin_t[pi + 1];
+              const float a0 = v0, b0 = v1, a1 = v2, b1 = v3;
+              v0 = a0 * c0 - b0 * s0;
+              v1 = b0 * c0 + a0 * s0;
+              v2 = a1 * c1 - b1 * s1;
+              v3 = b1 * c1 + a1 * s1;
+            }
+            o[0] = f2bf(v0); o[1] = f2bf(v1); o[2] = f2bf(v2); o[3] = f2bf(v3);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
+          }
           const int c = bh * 4 + g;  // 16-byte chunk of the 64-column row; this lane fills half `hi` of it
           *reinterpret_cast<bf16x4_t*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4) + hi * 8) = o;
         }
@@ -537,7 +565,8 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
 
 // variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
-                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, hipStream_t s) {
+                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
+                            int rope_T, int rope_cols, hipStream_t s) {
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -555,12 +584,16 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const bool stag = variant >= 5 || (variant == 0 && auto_stag);
   const int ntiles = tm * (use256 ? tn256 : tn128);
   const dim3 grid(ntiles < g_num_cus ? ntiles : g_num_cus);
-#define PLM_NTB(BN_, WM_, WN_, ST_, TN_) \
-  hipLaunchKernelGGL((gemm_nt_big_kernel<256, BN_, WM_, WN_, ST_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, TN_)
-  if (use256) {
-    if (stag) PLM_NTB(256, 2, 4, true, tn256); else PLM_NTB(256, 2, 4, false, tn256);
+  const RopeArgs rope{rope_cos, rope_sin, rope_T, rope_cols};
+#define PLM_NTB(BN_, WM_, WN_, ST_, RP_, TN_)                                                                                          \
+  hipLaunchKernelGGL((gemm_nt_big_kernel<256, BN_, WM_, WN_, ST_, RP_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, \
+                     alpha_dev, tm, TN_, rope)
+  if (rope_cos) {  // fused-RoPE epilogue (non-staggered schedule only)
+    if (use256) PLM_NTB(256, 2, 4, false, true, tn256); else PLM_NTB(128, 4, 2, false, true, tn128);
+  } else if (use256) {
+    if (stag) PLM_NTB(256, 2, 4, true, false, tn256); else PLM_NTB(256, 2, 4, false, false, tn256);
   } else {
-    if (stag) PLM_NTB(128, 4, 2, true, tn128); else PLM_NTB(128, 4, 2, false, tn128);
+    if (stag) PLM_NTB(128, 4, 2, true, false, tn128); else PLM_NTB(128, 4, 2, false, false, tn128);
   }
 #undef PLM_NTB
   return true;

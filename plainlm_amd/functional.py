@@ -69,6 +69,24 @@ class LinearFn(torch.autograd.Function):
     return dx, dw, None
 
 
+class QKVRopeFn(torch.autograd.Function):
+  """w_qkv projection + RoPE (transformer.py:42-47): returns the projection with q | k ALREADY rotated.
+  Contract with AttnFn: AttnFn.backward returns the gradient w.r.t. the UN-rotated projection (the inverse
+  rotation is folded into the attention backward epilogues), so this backward is the plain Linear backward."""
+
+  @staticmethod
+  def forward(ctx, x, weight, lin, cos, sin, B, T, nh):
+    wb, _ = lin.shadow()
+    ctx.save_for_backward(x)
+    ctx.lin = lin
+    return ops.qkv_rope(x, wb, cos, sin, B, T, nh)
+
+  @staticmethod
+  def backward(ctx, dy):
+    dx, dw, _ = LinearFn.backward(ctx, dy)
+    return dx, dw, None, None, None, None, None, None
+
+
 class EmbedFn(torch.autograd.Function):
   """nn.Embedding (transformer.py:94,110): fp32 row gather; backward = atomic scatter-add."""
 
@@ -166,9 +184,7 @@ class AttnFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, qkv, cos, sin, doc_start, B, T, nh):
-    # q, k are rotated in place in the projection output (this Function is its only consumer); the rotated
-    # buffer is what backward re-reads, and attn_bwd returns the gradient w.r.t. the un-rotated projection.
-    ops.rope_qk_(qkv, cos, sin, B, T, nh)
+    # qkv arrives with q, k already rotated (QKVRopeFn); attn_bwd returns the gradient w.r.t. the UN-rotated projection.
     out, lse = ops.attn_fwd(qkv, B, T, nh, doc_start)
     ctx.save_for_backward(qkv, out, lse, cos, sin)
     ctx.doc_start = doc_start

@@ -229,6 +229,20 @@ def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
   return qkv
 
 
+def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
+  """qkv[M, 3d] = x @ w_qkv^T with q | k rotated (RoPE fused into the GEMM epilogue when the shape allows)."""
+  _need(x, BF16, 'qkv_rope.x', 2)
+  _need(w_qkv, BF16, 'qkv_rope.w', 2)
+  M, K = x.shape
+  N = w_qkv.shape[0]
+  hd = N // (3 * nh)
+  out = torch.empty((M, N), dtype=BF16, device=x.device)
+  with _Timed('gemm_nt', 2.0 * M * N * K):
+    _lib.check(_lib.load().plm_qkv_rope_bf16(_p(x), x.stride(0), _p(w_qkv), w_qkv.stride(0), _p(out), N, M, K, _p(rope_cos),
+                                             _p(rope_sin), B, T, nh, hd, _stream()), 'plm_qkv_rope_bf16')
+  return out
+
+
 def attn_fwd(qkv_rot, B, T, nh, doc_start=None):
   """qkv_rot: projection output with q, k already rotated (rope_qk_)."""
   _need(qkv_rot, BF16, 'attn_fwd.qkv', 2)

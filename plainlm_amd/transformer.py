@@ -142,7 +142,7 @@ class Attention(nn.Module):
     self.w_out = HipLinear(cfg.dim, cfg.dim)
 
   def forward(self, x2d, rope, doc_start, B, T):
-    qkv = self.w_qkv(x2d)
+    qkv = Fn.QKVRopeFn.apply(x2d, self.w_qkv.weight, self.w_qkv, rope[0], rope[1], B, T, self.n_heads)
     a = Fn.AttnFn.apply(qkv, rope[0], rope[1], doc_start, B, T, self.n_heads)
     return self.w_out(a)
 

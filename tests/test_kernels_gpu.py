@@ -298,6 +298,21 @@ def test_rope_qk_golden(ops, golden_dir):
   assert (qkv[:, 2 * d:] == 1).all()  # v untouched
 
 
+@pytest.mark.parametrize('B,T,nh,K', [(4, 256, 2, 128), (8, 1024, 12, 768), (3, 100, 1, 64)])
+def test_qkv_projection_with_fused_rope(ops, B, T, nh, K):
+  """Projection + RoPE in the GEMM epilogue (big shapes) or GEMM + in-place pass (small ones) vs the oracle."""
+  g = torch.Generator().manual_seed(B * T + nh)
+  d = nh * 64
+  x = bf(torch.randn(B * T, K, generator=g))
+  w = bf(0.1 * torch.randn(3 * d, K, generator=g))
+  cos, sin = O.rope_table(64, T)
+  y = x.float() @ w.float().t()
+  q, k, v = (t.reshape(B, T, nh, 64) for t in y.split(d, dim=1))
+  ref = torch.cat([O.rope_apply(q, cos, sin).reshape(B * T, d), O.rope_apply(k, cos, sin).reshape(B * T, d), v.reshape(B * T, d)], dim=1)
+  got = ops.qkv_rope(x.cuda(), w.cuda(), cos.cuda(), sin.cuda(), B, T, nh)
+  close(got.float(), ref, 8e-3, 'qkv projection + rope')
+
+
 def test_attention_softmax_rescale_branch(ops):
   """Force a large running-max jump late in the row (guide rule: rare data-dependent branch needs its own test)."""
   B, T, nh, d = 1, 256, 1, 64
