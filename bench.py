@@ -91,6 +91,8 @@ def main():
   ap.add_argument('--no-extras', action='store_true', help='skip the untimed roofline / full-step / cpu legs')
   ap.add_argument('--comm', default=None, choices=[None, 'rccl', 'torch'])
   ap.add_argument('--bucket-mb', type=float, default=64)
+  ap.add_argument('--doc-mask', action='store_true',
+                  help='BASELINE configs[4]: document-boundary attention masks (random documents, mean length ~256)')
   a = ap.parse_args()
 
   rank = int(os.environ.get('RANK', 0))
@@ -127,16 +129,29 @@ def main():
   n_pool = 4
   rng = np.random.default_rng(1234)
   tok = torch.from_numpy(rng.integers(0, V, size=(n_pool * B * world, T + 1)))[rank::world]
-  pool = [(tok[i * B:(i + 1) * B, :T].contiguous().to(device), tok[i * B:(i + 1) * B, 1:].contiguous().to(device))
-          for i in range(n_pool)]
+  def doc_starts(nrows):
+    """per row: document lengths ~ geometric(1/256) truncated so they sum to T+1 (data_prep_utils.py:52-77), as doc_start[B,T]"""
+    from plainlm_amd.engine import doc_start_from_lengths
+    docs = []
+    for _ in range(nrows):
+      lens, tot = [], 0
+      while tot < T + 1:
+        n = int(min(rng.geometric(1.0 / 256.0), T + 1 - tot))
+        lens.append(n)
+        tot += n
+      docs.append(lens)
+    return doc_start_from_lengths(docs, T).to(device)
+
+  pool = [(tok[i * B:(i + 1) * B, :T].contiguous().to(device), tok[i * B:(i + 1) * B, 1:].contiguous().to(device),
+           doc_starts(B) if a.doc_mask else None) for i in range(n_pool)]
 
   def fwd_bwd(i):
-    ids, tgt = pool[i % n_pool]
+    ids, tgt, dstart = pool[i % n_pool]
     model.sink.begin_window()
     if reducer is not None:
       reducer.begin(sync=True)
     model.invalidate_shadows()  # a real step changes the weights: redo the bf16 casts every step like autocast
-    loss = model.loss(ids, tgt)
+    loss = model.loss(ids, tgt, dstart)
     loss.backward()
     if reducer is not None:
       reducer.finish()
@@ -173,7 +188,8 @@ def main():
     'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
     'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
     'config': {'workload': f'plainLM {a.config} decoder ({c["n_layers"]}L d={c["d_model"]} nh={c["n_heads"]} h={hidden} V={V}) '
-                           f'fwd+bwd incl. per-step weight casts' + (' + bucketed RCCL grad all-reduce' if world > 1 else ''),
+                           f'fwd+bwd incl. per-step weight casts' + (' + bucketed RCCL grad all-reduce' if world > 1 else '')
+                           + (', document-boundary masks (mean doc length 256)' if a.doc_mask else ''),
                'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}'},
     'tokens_per_sec_per_gpu': round(value / world, 1),
     'mfu_bf16': round(value / world * fpt / (PEAK_BF16_TFLOPS * 1e12), 4),

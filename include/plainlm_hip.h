@@ -133,6 +133,10 @@ int plm_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, void* s
 int plm_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float bc1, float bc2, const float* clip_coef_dev, void* stream);
 
+/* Leave `n` CUs free when sizing the persistent GEMM grids (one workgroup per CU, static tile schedule), so that
+ * concurrently running RCCL collectives do not push GEMM workgroups into a second round.  Process-wide; 0 = whole chip. */
+int plm_set_cu_reserve(int n);
+
 /* ---- RCCL data-parallel gradient exchange (replaces DDP: engine/engine.py:64-65,104-105)
  * One communicator per process (one process per GPU).  uid is the 128-byte ncclUniqueId
  * produced by plm_comm_unique_id on rank 0 and shipped to the other ranks by the host. */

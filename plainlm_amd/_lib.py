@@ -47,6 +47,7 @@ SIGNATURES = {
   'plm_mean_f32': (_I, [_P, _P, _I64, _P]),
   'plm_sumsq_f32': (_I, [_P, _I64, _P, _P, _P]),
   'plm_adamw_f32': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+  'plm_set_cu_reserve': (_I, [_I]),
   'plm_comm_unique_id': (_I, [_P]),
   'plm_comm_init': (_I, [C.POINTER(_P), _P, _I, _I, _I]),
   'plm_comm_destroy': (_I, [_P]),

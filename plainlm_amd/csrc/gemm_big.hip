@@ -43,6 +43,25 @@ __device__ __forceinline__ void phase_barrier() { asm volatile("s_waitcnt lgkmcn
 #define BIG_GROUP_M 4
 
 static int g_num_cus = 0;
+static int g_cu_reserve = 0;  // CUs left free for concurrent kernels (RCCL collectives during backward)
+
+// number of persistent workgroups to launch: one per CU minus the reserve
+static int persistent_slots() {
+  const int n = g_num_cus - g_cu_reserve;
+  return n < 8 ? 8 : n;
+}
+
+// The persistent GEMMs launch one workgroup per CU with a static tile schedule.  A concurrent kernel that occupies
+// some CUs (RCCL's all-reduce on the side stream) would push the displaced workgroups into a second round; leaving
+// `n` CUs free avoids that.  Process-wide setting; 0 restores the full chip.
+extern "C" int plm_set_cu_reserve(int n) {
+  if (n < 0 || n > 128) {
+    plm_set_error("plm_set_cu_reserve: n=%d out of range 0..128", n);
+    return PLM_E_INVALID;
+  }
+  g_cu_reserve = n;
+  return PLM_OK;
+}
 
 static double round_efficiency(int64_t tiles, int slots) {
   const int64_t rounds = (tiles + slots - 1) / slots;
@@ -535,13 +554,14 @@ bool plm_tn_big_plan(int64_t M, int64_t N, int64_t K, int* splits, int* rfull) {
   if (K % 64 != 0 || M < 256 || N < 256) return false;
   const int64_t R = plm_cdiv(M, 256), Cn = plm_cdiv(N, 256), tiles = R * Cn;
   const int64_t max_by_k = K / 512 > 0 ? K / 512 : 1;  // >= 8 K-tiles per item
+  const int64_t slots = persistent_slots();
   int64_t rf = 0, s = 1;
-  if (tiles < g_num_cus) {
-    s = g_num_cus / tiles;
+  if (tiles < slots) {
+    s = slots / tiles;
   } else {
-    rf = ((tiles / g_num_cus) * g_num_cus) / Cn;
+    rf = ((tiles / slots) * slots) / Cn;
     const int64_t rem = (R - rf) * Cn;
-    s = rem > 0 ? g_num_cus / rem : 1;
+    s = rem > 0 ? slots / rem : 1;
   }
   if (s > max_by_k) s = max_by_k;
   if (s < 1) s = 1;
@@ -556,7 +576,8 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const int tm = (int)plm_cdiv(M, 256), tn = (int)plm_cdiv(N, 256);
   const int kchunk = (int)(plm_cdiv(plm_cdiv(K, splits), 64) * 64);
   const int nitems = rfull * tn + (tm - rfull) * tn * splits;
-  const dim3 grid(nitems < g_num_cus ? nitems : g_num_cus), block(512);
+  const int slots = persistent_slots();
+  const dim3 grid(nitems < slots ? nitems : slots), block(512);
   hipLaunchKernelGGL(gemm_tn_big_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
                      accumulate, alpha_dev, tm, tn);
 }
@@ -575,8 +596,9 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   }
   const int tm = (int)plm_cdiv(M, 256);
   const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128);
-  const double e256 = round_efficiency((int64_t)tm * tn256, g_num_cus) * ((double)N / (tn256 * 256.0));
-  const double e128 = round_efficiency((int64_t)tm * tn128, g_num_cus) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
+  const int slots = persistent_slots();
+  const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
+  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.7 && e128 < 0.7))) return false;
   const dim3 block(512);
   static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default

@@ -20,10 +20,18 @@ import torch.distributed as dist
 from . import _lib
 
 
+# CUs kept free for RCCL's kernels while gradients are exchanged during backward, and the matching cap on RCCL
+# channels (one workgroup each).  160M fp32 gradients are 650 MB per step: even 8 channels move that well inside a
+# ~25 ms backward over xGMI, and the persistent GEMMs keep a whole number of rounds on the remaining CUs.
+COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
+
+
 class RcclComm:
   """Direct RCCL communicator (one per process = one per GPU)."""
 
   def __init__(self, rank, world_size, device_index, store_group=None):
+    if world_size > 1:
+      os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
     lib = _lib.load()
     uid = (C.c_uint8 * 128)()
     if rank == 0:
@@ -37,6 +45,8 @@ class RcclComm:
     _lib.check(lib.plm_comm_init(C.byref(handle), C.cast(uid, C.c_void_p), rank, world_size, device_index), 'plm_comm_init')
     self.handle, self.lib = handle, lib
     self.rank, self.world_size = rank, world_size
+    if world_size > 1:
+      _lib.check(lib.plm_set_cu_reserve(COMM_CUS), 'plm_set_cu_reserve')
 
   def allreduce_avg_(self, span, stream):
     _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),
