@@ -6,6 +6,8 @@
 // in place: algorithmic traffic = 2*V bytes read + 2*V bytes written per row.
 #include "plm_device.h"
 
+#define LOG2E_F 1.4426950408889634f
+
 struct MaxSum {
   float m, s;
 };
@@ -53,19 +55,24 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(uint16_t* __restrict__
   float xt = 0.f;
   if (tgt_ok) xt = bf2f(reinterpret_cast<const bf16_t*>(lr)[tgt]);  // read before anything is overwritten
 
-  bf16x8_t v[NCH];
+  u32x4_t v[NCH];  // the row stays in registers as packed bf16 pairs
   MaxSum acc{-INFINITY, 0.f};
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = threadIdx.x + 1024 * i;
     if (c < nvec) {
-      v[i] = ld_bf16x8(lr + c * 8);
-      float mx = bf2f(v[i][0]);
+      v[i] = *reinterpret_cast<const u32x4_t*>(lr + c * 8);
+      float f[8];
 #pragma unroll
-      for (int e = 1; e < 8; ++e) mx = fmaxf(mx, bf2f(v[i][e]));
+      for (int w = 0; w < 4; ++w) {
+        f[2 * w] = bf_lo(v[i][w]);
+        f[2 * w + 1] = bf_hi(v[i][w]);
+      }
+      float mx = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
+      const float mxl = mx * LOG2E_F;
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += __expf(bf2f(v[i][e]) - mx);
+      for (int e = 0; e < 8; ++e) s += __builtin_amdgcn_exp2f(f[e] * LOG2E_F - mxl);
       acc = ms_combine(acc, MaxSum{mx, s});
     }
   }
@@ -73,20 +80,28 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(uint16_t* __restrict__
   const float lse = tot.m + __logf(tot.s);
   if (threadIdx.x == 0) loss_rows[row] = tgt_ok ? (lse - xt) : 0.f;
   const float gs = tgt_ok ? grad_scale : 0.f;  // ignored rows get zero gradient
+  const float lsel = lse * LOG2E_F;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = threadIdx.x + 1024 * i;
     if (c < nvec) {
-      bf16x8_t o;
+      float p[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float p = __expf(bf2f(v[i][e]) - lse);
-        if ((int64_t)c * 8 + e == tgt) p -= 1.f;
-        o[e] = f2bf(p * gs);
+      for (int w = 0; w < 4; ++w) {
+        p[2 * w] = __builtin_amdgcn_exp2f(bf_lo(v[i][w]) * LOG2E_F - lsel);
+        p[2 * w + 1] = __builtin_amdgcn_exp2f(bf_hi(v[i][w]) * LOG2E_F - lsel);
       }
-      st_bf16x8(lr + c * 8, o);
+      u32x4_t o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) o[w] = pack_bf2(p[2 * w] * gs, p[2 * w + 1] * gs);
+      *reinterpret_cast<u32x4_t*>(lr + c * 8) = o;
     }
   }
+  // the target column gets softmax - 1: one 2-byte fix-up after the vector stores (ordered by the barrier) instead of
+  // a compare + select on every element of every chunk
+  __syncthreads();
+  if (threadIdx.x == 0 && tgt_ok)
+    reinterpret_cast<bf16_t*>(lr)[tgt] = f2bf((__builtin_amdgcn_exp2f(xt * LOG2E_F - lsel) - 1.f) * gs);
   // zero the pad columns V..ld (ld - V < 64)
   for (int64_t c = V + threadIdx.x; c < ld; c += 1024) lr[c] = 0;
 }

@@ -294,8 +294,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
             float v0 = acc[mf][bh][4 * g + 0] * alpha, v1 = acc[mf][bh][4 * g + 1] * alpha;
             float v2 = acc[mf][bh][4 * g + 2] * alpha, v3 = acc[mf][bh][4 * g + 3] * alpha;
             if (ncol < rope.cols) {
-              const int pi = tpos * 32 + (ncol & 63) / 2;
-              const float c0 = rope.cos_t[pi], c1 = rope.cos_t[pi + 1], s0 = rope.sin_t[pi], s1 = rope.sin_t[pi + 1];
+              const int pi = tpos * 32 + (ncol & 63) / 2;  // even: the two pairs' table entries are one aligned 8-byte load each
+              typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+              const f32x2_t cc = *reinterpret_cast<const f32x2_t*>(rope.cos_t + pi);
+              const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(rope.sin_t + pi);
+              const float c0 = cc[0], c1 = cc[1], s0 = ss[0], s1 = ss[1];
               const float a0 = v0, b0 = v1, a1 = v2, b1 = v3;
               v0 = a0 * c0 - b0 * s0;
               v1 = b0 * c0 + a0 * s0;

@@ -60,6 +60,17 @@ __device__ __forceinline__ bf16x8_t zero_bf16x8() {
   return __builtin_bit_cast(bf16x8_t, z);
 }
 
+// Two bf16 packed in one dword -> two floats with ONE VALU op each (shift / mask), and back with one
+// v_cvt_pk_bf16_f32 per pair.  Element-wise access to bf16 ext-vectors makes hipcc shuffle lanes with v_perm_b32.
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  bf16x2_t t;
+  t[0] = (bf16_t)lo;
+  t[1] = (bf16_t)hi;
+  return __builtin_bit_cast(unsigned, t);
+}
+
 // full-wave (64 lanes) reductions; every lane receives the result
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
