@@ -81,7 +81,10 @@ struct RopeArgs {
   int cols;
 };
 
-template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE>
+// ONEBAR: all four half-tiles of the next K-tile are issued at the top of the current one and the quadrants run
+// back-to-back with a single s_waitcnt vmcnt(0) + barrier per K-tile (the compiler is then free to interleave the
+// ds_reads of later quadrants with the MFMAs of earlier ones).
+template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -204,10 +207,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       // end of a phase's READ section / MFMA section
       auto end_read = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
+        if (ONEBAR) return;
         if (more) wait_vm<W>(); else wait_vm<0>();
         phase_barrier();
         if (STAG) __builtin_amdgcn_s_setprio(1);
       };
+      if (ONEBAR && more) {  // the whole next K-tile goes in flight now
+        issue_a(0, nxt, s_k);
+        issue_b(0, nxt, s_k);
+        issue_b(1, nxt, s_k);
+        issue_a(1, nxt, s_k);
+      }
       auto end_mfma = [&]() {
         if (STAG) {
           __builtin_amdgcn_s_setprio(0);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       using std::integral_constant;
 
       // ---- phase 1: quadrant (A0, B0); stage A0 of the next item
-      if (more) issue_a(0, nxt, s_k);
+      if (!ONEBAR && more) issue_a(0, nxt, s_k);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         b0[ks] = frag(cur + OFF_B0, wn * 32 + l31, ks);
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       if (STAG) end_mfma(); else end_read(integral_constant<int, W_P1>{});
 
       // ---- phase 2: quadrant (A0, B1); stage B0
-      if (more) issue_b(0, nxt, s_k);
+      if (!ONEBAR && more) issue_b(0, nxt, s_k);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
       if (STAG) end_read(integral_constant<int, W_P2>{});
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       if (STAG) end_mfma(); else end_read(integral_constant<int, W_P2>{});
 
       // ---- phase 3: quadrant (A1, B1); stage B1.  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
-      if (more) issue_b(1, nxt, s_k);
+      if (!ONEBAR && more) issue_b(1, nxt, s_k);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       if (STAG) end_mfma();
 
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1
-      if (more) issue_a(1, nxt, s_k);
+      if (!ONEBAR && more) issue_a(1, nxt, s_k);
       if (STAG) {
         if (more) advance_staged();
         end_read(integral_constant<int, W_P4>{});
@@ -270,6 +280,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(b0[ks], a[f][ks], acc[AF + f][0]);
       if (STAG) {
         end_mfma();
+      } else if (ONEBAR) {
+        if (more) advance_staged();
+        wait_vm<0>();
+        phase_barrier();
       } else {
         if (more) advance_staged();
         end_read(integral_constant<int, W_P4>{});
@@ -587,7 +601,8 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
 
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
-// variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered
+// variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered,
+// 7 / 8 = the same with one barrier per K-tile
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
                             int rope_T, int rope_cols, hipStream_t s) {
@@ -605,8 +620,10 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.7 && e128 < 0.7))) return false;
   const dim3 block(512);
   static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default
-  const bool use256 = variant == 3 || variant == 5 || (variant == 0 && e256 >= e128);
-  const bool stag = variant >= 5 || (variant == 0 && auto_stag);
+  static const bool auto_onebar = getenv("PLM_GEMM_ONEBAR") != nullptr;
+  const bool use256 = variant == 3 || variant == 5 || variant == 7 || (variant == 0 && e256 >= e128);
+  const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
+  const bool onebar = variant >= 7 || (variant == 0 && auto_onebar);
   const int ntiles = tm * (use256 ? tn256 : tn128);
   const dim3 grid(ntiles < g_num_cus ? ntiles : g_num_cus);
   const RopeArgs rope{rope_cos, rope_sin, rope_T, rope_cols};
@@ -615,6 +632,13 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
                      alpha_dev, tm, TN_, rope)
   if (rope_cos) {  // fused-RoPE epilogue (non-staggered schedule only)
     if (use256) PLM_NTB(256, 2, 4, false, true, tn256); else PLM_NTB(128, 4, 2, false, true, tn128);
+  } else if (onebar) {
+    if (use256)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                         (int)K, alpha_dev, tm, tn256, rope);
+    else
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                         (int)K, alpha_dev, tm, tn128, rope);
   } else if (use256) {
     if (stag) PLM_NTB(256, 2, 4, true, false, tn256); else PLM_NTB(256, 2, 4, false, false, tn256);
   } else {
