@@ -617,10 +617,14 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const int slots = persistent_slots();
   const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
   const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
-  if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.7 && e128 < 0.7))) return false;
+  // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
+  // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
+  if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
   const dim3 block(512);
   static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default
-  static const bool auto_onebar = getenv("PLM_GEMM_ONEBAR") != nullptr;
+  // measured (profiles/r01_kbench_run13_*): one barrier per K-tile is 5-14 % faster for K <= 2304, the 4-phase
+  // counted-wait schedule ~10 % faster for K >= 4096
+  const bool auto_onebar = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
   const bool use256 = variant == 3 || variant == 5 || variant == 7 || (variant == 0 && e256 >= e128);
   const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
   const bool onebar = variant >= 7 || (variant == 0 && auto_onebar);
@@ -630,8 +634,15 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
 #define PLM_NTB(BN_, WM_, WN_, ST_, RP_, TN_)                                                                                          \
   hipLaunchKernelGGL((gemm_nt_big_kernel<256, BN_, WM_, WN_, ST_, RP_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, \
                      alpha_dev, tm, TN_, rope)
-  if (rope_cos) {  // fused-RoPE epilogue (non-staggered schedule only)
-    if (use256) PLM_NTB(256, 2, 4, false, true, tn256); else PLM_NTB(128, 4, 2, false, true, tn128);
+  if (rope_cos) {  // fused-RoPE epilogue (non-staggered schedules only)
+    if (onebar) {
+      if (use256)
+        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                           (int)K, alpha_dev, tm, tn256, rope);
+      else
+        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                           (int)K, alpha_dev, tm, tn128, rope);
+    } else if (use256) PLM_NTB(256, 2, 4, false, true, tn256); else PLM_NTB(128, 4, 2, false, true, tn128);
   } else if (onebar) {
     if (use256)
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
