@@ -59,8 +59,10 @@ def build_model(c, device, seed=100):
   return model.to(device)
 
 
-def cpu_baseline(c, budget_s=25.0):
-  """Oracle (oracle/cpu_ref.py, fp32 eager) fwd+bwd on the host cores: B=1 sequences of seq_len tokens."""
+def cpu_baseline(c, budget_s=28.0):
+  """Oracle (oracle/cpu_ref.py, fp32 eager) fwd+bwd on the host cores: B=1 sequences of seq_len tokens.
+  More threads is not faster for this eager fp32 graph (oversubscription on big hosts), so a few thread counts are
+  tried (one iteration each) and the best one is used for the timed sample; ``cores`` is the count actually used."""
   from oracle import cpu_ref as O
   ocfg = O.OracleConfig(vocab_size=c['vocab_size'], seq_len=c['seq_len'], dim=c['d_model'], n_layers=c['n_layers'],
                         n_heads=c['n_heads'])
@@ -68,17 +70,33 @@ def cpu_baseline(c, budget_s=25.0):
   rng = np.random.default_rng(1234)
   tok = torch.from_numpy(rng.integers(0, c['vocab_size'], size=(1, c['seq_len'] + 1)))
   ids, tgt = tok[:, :-1], tok[:, 1:]
-  cores = torch.get_num_threads()
-  O.loss_and_grads(params, ocfg, ids, tgt)  # warm-up
-  times, t_all = [], time.time()
-  while len(times) < 5 and (time.time() - t_all) < budget_s:
+  ncpu = os.cpu_count() or 1
+  t_all = time.time()
+
+  def one():
     t0 = time.time()
     O.loss_and_grads(params, ocfg, ids, tgt)
-    times.append(time.time() - t0)
+    return time.time() - t0
+
+  default_threads = torch.get_num_threads()
+  one()  # warm-up (allocations, thread pool)
+  best_n, best_t = None, None
+  for n in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+    if time.time() - t_all > 0.5 * budget_s and best_n is not None:
+      break
+    torch.set_num_threads(n)
+    dt = one()
+    if best_t is None or dt < best_t:
+      best_n, best_t = n, dt
+  torch.set_num_threads(best_n)
+  times = [best_t]
+  while len(times) < 5 and (time.time() - t_all) < budget_s:
+    times.append(one())
+  torch.set_num_threads(default_threads)
   med = float(np.median(times))
-  return {'value': round(c['seq_len'] / med, 1), 'unit': 'tokens/s', 'cores': cores, 'kind': 'port',
+  return {'value': round(c['seq_len'] / med, 1), 'unit': 'tokens/s', 'cores': best_n, 'kind': 'port',
           'sample': f'oracle/cpu_ref.py fp32 eager fwd+bwd, batch 1 x {c["seq_len"]} tokens, median of {len(times)} iterations '
-                    f'after 1 warm-up, torch threads={cores}'}
+                    f'at the fastest of 16/32/64/{ncpu} torch threads (= {best_n}) on a {ncpu}-CPU host'}
 
 
 def main():
@@ -219,14 +237,18 @@ def main():
 
     # ---- full training step (clip + AdamW) for reference, same data (untimed leg) ----
     if rank == 0 or world > 1:
-      opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.1, fused=True)
+      # the engine's optimizer tail (plainlm_amd/optim.py): ||g|| reduction + clip folded into one fused AdamW launch per
+      # weight-decay group, on flat buffers.  NOTE: it re-lays parameters/gradients, so it runs after the legs above.
+      import plainlm_amd as P
+      from plainlm_amd.optim import FlatAdamW
+      opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
+      if reducer is not None:
+        reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb)
+        model.sink.on_ready = reducer.param_ready
 
       def full(i):
         fwd_bwd(i)
-        model.attach_grads()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
-        opt.zero_grad(set_to_none=True)
+        opt.clip_and_step(1.0)
 
       for i in range(2):
         full(i)
@@ -238,7 +260,7 @@ def main():
       torch.cuda.synchronize()
       full_ms = 1e3 * (time.perf_counter() - t1) / nfull
       out['full_step'] = {'ms_per_step': round(full_ms, 3), 'tokens_per_sec_per_gpu': round(B * T / full_ms * 1e3, 1),
-                          'note': 'fwd+bwd + clip_grad_norm_ + torch fused AdamW (rank-local clock, untimed leg)'}
+                          'note': 'fwd+bwd + global-norm clip + AdamW (plainlm_amd FlatAdamW kernels; rank-local clock, untimed leg)'}
 
     if world == 1:
       out['cpu_baseline'] = cpu_baseline(c)

@@ -85,11 +85,13 @@ class TorchDistComm:
 
 
 def plan_buckets(spans, cap_bytes):
-  """spans: [(offset, numel)] in parameters() order.  Returns buckets as (lo, hi, [param idx])
-  built from the LAST parameter backwards (the order gradients become ready), each at most
-  cap_bytes unless a single parameter is larger (it then forms its own bucket)."""
+  """spans: [(offset, numel)] per parameter (any order, together tiling the flat buffer without gaps).
+  Returns buckets as (lo, hi, [param idx]): contiguous regions of the flat buffer, built from its END backwards
+  (the flat layout follows parameters() order, so the end holds the gradients that become ready first), each at
+  most cap_bytes unless a single parameter is larger (it then forms its own bucket)."""
+  order = sorted(range(len(spans)), key=lambda i: spans[i][0], reverse=True)
   buckets, cur, cur_bytes = [], [], 0
-  for idx in range(len(spans) - 1, -1, -1):
+  for idx in order:
     nbytes = spans[idx][1] * 4
     if cur and cur_bytes + nbytes > cap_bytes:
       buckets.append(cur)

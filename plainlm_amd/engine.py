@@ -91,12 +91,18 @@ def initialize_scheduler(optimizer, cfg):
   raise NotImplementedError(f'Not implemented scheduler: {name}.')
 
 
-def intialize_optimizer(param_groups, cfg):
-  """(sic) optim/init_optim.py:7-21 — AdamW is the only optimizer on the shipped configs' path."""
+def intialize_optimizer(param_groups, cfg, model=None):
+  """(sic) optim/init_optim.py:7-21 — AdamW is the only optimizer on the shipped configs' path.
+  ``fused_optim: True`` (the shipped configs) selects FlatAdamW: clip + AdamW on flat buffers with our kernels;
+  ``False`` keeps torch.optim.AdamW on the per-parameter views."""
   if cfg.optim != 'adamw':
     raise NotImplementedError(f'Not implemented optim: {cfg.optim}.')
+  if bool(getattr(cfg, 'fused_optim', True)) and model is not None:
+    from .optim import FlatAdamW
+    return FlatAdamW(model, param_groups, lr=cfg.lr, betas=[cfg.beta1, cfg.beta2], eps=getattr(cfg, 'eps', 1e-8),
+                     weight_decay=cfg.weight_decay)
   return torch.optim.AdamW(param_groups, lr=cfg.lr, betas=[cfg.beta1, cfg.beta2], weight_decay=cfg.weight_decay,
-                           fused=bool(getattr(cfg, 'fused_optim', True)), eps=getattr(cfg, 'eps', 1e-8))
+                           eps=getattr(cfg, 'eps', 1e-8))
 
 
 def doc_start_from_lengths(docs_lengths, seq_len):
@@ -153,6 +159,12 @@ class HipEngine(torch.nn.Module):
     flat = self.model.enable_main_grad()
     self.params = list(self.model.parameters())
 
+    # optimizer first: FlatAdamW re-lays parameters / gradients into one span per weight-decay group
+    self.scaler = torch.amp.GradScaler(enabled=False)  # bf16 needs no loss scaling; kept for checkpoint layout
+    param_groups = get_param_groups(model, cfg.weight_decay)
+    self.optimizer = intialize_optimizer(param_groups, cfg, self.model)
+    self.scheduler = initialize_scheduler(self.optimizer, cfg)
+
     self.reducer = None
     if dist.is_initialized() and dist.get_world_size() > 1:
       comm = ddp.make_comm(device, comm_backend)
@@ -161,10 +173,6 @@ class HipEngine(torch.nn.Module):
       self.model.invalidate_shadows()
       self.model.sink.on_ready = self.reducer.param_ready
 
-    self.scaler = torch.amp.GradScaler(enabled=False)  # bf16 needs no loss scaling; kept for checkpoint layout
-    param_groups = get_param_groups(model, cfg.weight_decay)
-    self.optimizer = intialize_optimizer(param_groups, cfg)
-    self.scheduler = initialize_scheduler(self.optimizer, cfg)
     if getattr(cfg, 'resume', False):
       self.optimizer.load_state_dict(ckpt['optimizer'])
       self.scheduler.load_state_dict(ckpt['scheduler'])
@@ -192,10 +200,13 @@ class HipEngine(torch.nn.Module):
 
     if last:
       self.accumulated_samples = 0
-      self.model.attach_grads()
-      if self.grad_clip:
-        torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-      self.optimizer.step()
+      if hasattr(self.optimizer, 'clip_and_step'):
+        self.optimizer.clip_and_step(self.grad_clip or None)  # fused global-norm clip + AdamW on the flat buffers
+      else:
+        self.model.attach_grads()
+        if self.grad_clip:
+          torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+        self.optimizer.step()
       self.optimizer.zero_grad(set_to_none=True)
       if self.scheduler:
         self.scheduler.step()

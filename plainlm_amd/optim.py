@@ -1,0 +1,111 @@
+"""Optimizer tail on the gfx950 kernels (engine/engine.py:126-135, optim/init_optim.py:14-21).
+
+``FlatAdamW`` is a ``torch.optim.AdamW`` subclass, so ``engine.optimizer`` keeps the reference's interface
+(``param_groups`` with per-group ``lr`` written by the LR schedule, ``state_dict()`` / ``load_state_dict()`` in
+torch's layout: per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), but
+
+  * parameters, gradients and both moments live in flat fp32 buffers (one span per weight-decay group),
+  * ``clip_and_step(max_norm)`` = one deterministic ||g||^2 reduction + one fused AdamW launch per group; the
+    clip coefficient min(1, max_norm / (||g|| + 1e-6)) is computed on the device and folded into the AdamW
+    kernel, so clipping costs no extra pass over the gradients and no host synchronisation.
+
+Arithmetic matches ``torch.optim.AdamW`` (decoupled decay ``p *= 1 - lr*wd``; bias-corrected moments;
+``denom = sqrt(v)/sqrt(bc2) + eps``) and ``torch.nn.utils.clip_grad_norm_``.
+"""
+
+import torch
+
+from . import ops
+
+
+class FlatAdamW(torch.optim.AdamW):
+  def __init__(self, model, param_groups, lr, betas, eps, weight_decay):
+    super().__init__(param_groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, fused=False, foreach=False)
+    if getattr(model, '_flat_grad', None) is None:
+      raise RuntimeError('FlatAdamW needs model.enable_main_grad() first (flat gradient buffer)')
+    self.model = model
+    dev = model._flat_grad.device
+    # Re-lay parameters and gradients group by group so that every group is ONE contiguous span.
+    order = [p for g in self.param_groups for p in g['params']]
+    if len({id(p) for p in order}) != len(list(model.parameters())):
+      raise ValueError('param_groups must cover every model parameter exactly once')
+    total = sum(p.numel() for p in order)
+    self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+    self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.flat_g = model._flat_grad
+    if self.flat_g.numel() != total:
+      raise ValueError('flat gradient buffer does not match the parameter groups')
+    self.group_spans = []
+    self._views = {}
+    off = 0
+    spans_by_param = {}
+    for g in self.param_groups:
+      lo = off
+      for p in g['params']:
+        n = p.numel()
+        self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+        p.data = self.flat_p[off:off + n].view(p.shape)
+        p.main_grad = self.flat_g[off:off + n].view(p.shape)
+        spans_by_param[id(p)] = (off, n)
+        self._views[id(p)] = (self.flat_m[off:off + n].view(p.shape), self.flat_v[off:off + n].view(p.shape))
+        off += n
+      self.group_spans.append((lo, off))
+    # the model's span table (used by the gradient reducer) follows parameters() order
+    model._grad_spans = [spans_by_param[id(p)] for p in model.parameters()]
+    model.invalidate_shadows()
+    self._scratch = torch.empty(4096, dtype=torch.float32, device=dev)
+    self._step_count = 0
+    self.last_grad_norm = None
+    self._publish_state()
+
+  def _publish_state(self):
+    """torch-layout per-parameter state backed by views of the flat moment buffers."""
+    for g in self.param_groups:
+      for p in g['params']:
+        m, v = self._views[id(p)]
+        self.state[p] = {'step': torch.tensor(float(self._step_count)), 'exp_avg': m, 'exp_avg_sq': v}
+
+  @torch.no_grad()
+  def clip_and_step(self, max_norm=None):
+    self._step_count += 1
+    clip = None
+    if max_norm:
+      sq = ops.sumsq(self.flat_g, self._scratch)
+      self.last_grad_norm = torch.sqrt(sq)
+      clip = torch.clamp(float(max_norm) / (self.last_grad_norm + 1e-6), max=1.0).reshape(1).contiguous()
+    for g, (lo, hi) in zip(self.param_groups, self.group_spans):
+      if hi == lo:
+        continue
+      b1, b2 = g['betas']
+      ops.adamw_(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], float(g['lr']), b1, b2,
+                 g['eps'], g['weight_decay'], self._step_count, clip)
+    for st in self.state.values():
+      st['step'].fill_(float(self._step_count))
+    self.model.invalidate_shadows()  # raw-pointer update: torch's version counters did not move
+
+  @torch.no_grad()
+  def step(self, closure=None):
+    if closure is not None:
+      raise NotImplementedError('FlatAdamW.step does not take a closure')
+    self.clip_and_step(None)
+
+  def zero_grad(self, set_to_none=True):
+    # gradients live in the flat buffer and are overwritten by the first write of the next window
+    for g in self.param_groups:
+      for p in g['params']:
+        p.grad = None
+
+  def load_state_dict(self, state_dict):
+    super().load_state_dict(state_dict)
+    steps = []
+    for g in self.param_groups:
+      for p in g['params']:
+        st = self.state.get(p)
+        if st:
+          m, v = self._views[id(p)]
+          m.copy_(st['exp_avg'])
+          v.copy_(st['exp_avg_sq'])
+          steps.append(int(float(st['step'])))
+    self._step_count = max(steps) if steps else 0
+    self._publish_state()

@@ -146,6 +146,10 @@ def test_bucket_plan():
     spans.append((off, n))
     off += n
   b = ddp.plan_buckets(spans, cap_bytes=4 * 700)
+  # a permuted span table (FlatAdamW groups parameters by weight decay) still yields contiguous buckets
+  perm = [spans[i] for i in (2, 0, 5, 1, 4, 3)]
+  for lo, hi, idxs in ddp.plan_buckets(perm, cap_bytes=4 * 700):
+    assert hi - lo == sum(perm[i][1] for i in idxs)
   # last parameter first; oversize parameters alone; every bucket contiguous; full cover, no overlap
   assert b[0][2] == [5] and b[-1][2] == [0]
   covered = sorted((lo, hi) for lo, hi, _ in b)

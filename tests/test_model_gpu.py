@@ -269,3 +269,39 @@ def test_rccl_reducer_single_rank(P, mdl):
   assert torch.equal(m._flat_grad[emb:], want[emb:])
   assert relmax(m._flat_grad[:emb], want[:emb]) < 1e-5
   comm.close()
+
+
+def test_flat_adamw_matches_torch_adamw_and_clip(P, mdl):
+  """FlatAdamW.clip_and_step vs torch clip_grad_norm_ + torch.optim.AdamW over 3 steps (same grads), incl. the
+  torch-layout state_dict round trip (row N1)."""
+  from plainlm_amd.optim import FlatAdamW
+  m = _small(P, mdl, main_grad=True)
+  ref = _small(P, mdl)
+  groups = P.get_param_groups(m, 0.1)
+  opt = FlatAdamW(m, groups, lr=3e-3, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
+  ropt = torch.optim.AdamW(P.get_param_groups(ref, 0.1), lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+  g = torch.Generator(device='cuda').manual_seed(0)
+  for step in range(3):
+    for p, q in zip(m.parameters(), ref.parameters()):
+      grad = torch.randn(p.shape, device='cuda', generator=g) * (5.0 if step == 0 else 0.01)  # step 0 clips, later ones do not
+      p.main_grad.copy_(grad)
+      q.grad = grad.clone()
+    for grp in opt.param_groups + ropt.param_groups:
+      grp['lr'] = 3e-3 * (step + 1) / 3
+    opt.clip_and_step(1.0)
+    norm = torch.nn.utils.clip_grad_norm_(list(ref.parameters()), 1.0)
+    ropt.step()
+    assert abs(opt.last_grad_norm.item() - norm.item()) <= 1e-5 * norm.item()
+  for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+    assert relmax(p.detach(), q.detach()) < 2e-6, n
+  sd = opt.state_dict()
+  assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'} and len(sd['state']) == 15
+  rsd = ropt.state_dict()
+  assert relmax(sd['state'][3]['exp_avg'], rsd['state'][3]['exp_avg']) < 1e-5
+  opt.load_state_dict(sd)
+  assert opt._step_count == 3
+  # forward still works on the re-laid parameters and sees the updated weights
+  tok = mdl['tokens']
+  l1 = m.loss(tok[:, :64].cuda(), tok[:, 1:65].cuda()).item()
+  l2 = ref.loss(tok[:, :64].cuda(), tok[:, 1:65].cuda()).item()
+  assert abs(l1 - l2) <= 1e-4 * abs(l2)
