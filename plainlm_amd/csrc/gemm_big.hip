@@ -603,6 +603,9 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
 
 // variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered,
 // 7 / 8 = the same with one barrier per K-tile
+void plm_launch_gemm_nt_w4(int slots, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
+                           int64_t N, int64_t K, const float* alpha_dev, hipStream_t s);  // gemm_w4.hip
+
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
                             int rope_T, int rope_cols, hipStream_t s) {
@@ -621,6 +624,10 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
   const dim3 block(512);
+  if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip)
+    plm_launch_gemm_nt_w4(slots, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
+    return true;
+  }
   static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default
   // measured (profiles/r01_kbench_run13_*): one barrier per K-tile is 5-14 % faster for K <= 2304, the 4-phase
   // counted-wait schedule ~10 % faster for K >= 4096

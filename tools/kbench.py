@@ -66,7 +66,7 @@ def main():
       out = torch.empty(m, n, device=dev, dtype=BF)
       rec(name, timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
       if k % 64 == 0 and a.variants:
-        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128')):
+        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (9, 'w4_256x256')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
       del A, Bm, out
     for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
