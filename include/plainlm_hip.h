@@ -89,6 +89,13 @@ int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
 int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                         void* stream);
+/* nt with an optional caller-owned fp32 workspace (plm_gemm_nt_workspace_bytes; 0 = none needed): with it the automatic
+ * choice may use the hybrid whole-K + split-K schedule on 256x256 tiles, which removes the round quantisation of shapes
+ * such as N = 768 (384 tiles on 256 CUs).  Without a workspace the call behaves exactly like plm_gemm_bf16_nt_ex. */
+size_t plm_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
+                        int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
+                        void* workspace, size_t workspace_bytes, void* stream);
 size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int accumulate, const float* alpha_dev,

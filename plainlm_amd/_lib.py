@@ -37,6 +37,8 @@ SIGNATURES = {
   'plm_swiglu_bwd': (_I, [_P, _P, _P, _I64, _I64, _P]),
   'plm_gemm_bf16_nt': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _P]),
   'plm_gemm_bf16_nt_ex': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _I, _P]),
+  'plm_gemm_nt_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
+  'plm_gemm_bf16_nt_ws': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _I, _P, _SZ, _P]),
   'plm_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
   'plm_gemm_bf16_tn': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
   'plm_rope_qk': (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),

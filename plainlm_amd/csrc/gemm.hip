@@ -302,13 +302,13 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const uint16_t* __rest
 
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
-                            int rope_T, int rope_cols, hipStream_t s);  // gemm_big.hip
+                            int rope_T, int rope_cols, void* workspace, size_t workspace_bytes, hipStream_t s);  // gemm_big.hip
 extern "C" int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                            void* stream);
 
-extern "C" int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+extern "C" int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                                    int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
-                                   void* stream) {
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   PLM_REQUIRE(A && B && C, "plm_gemm_bf16_nt: null pointer");
   PLM_REQUIRE(variant >= 0 && variant <= 9, "plm_gemm_bf16_nt_ex: variant must be 0..9");
   PLM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "plm_gemm_bf16_nt: bad shape M=%ld N=%ld K=%ld",
@@ -328,7 +328,8 @@ extern "C" int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_
   PLM_REQUIRE(variant <= 2 || c_dtype == 0, "plm_gemm_bf16_nt_ex: the big-tile variants write bf16 C only");
   const bool dma_ok = variant >= 2 || (variant == 0 && !force_v1 && dma_shape);
   if ((variant == 0 && dma_ok && c_dtype == 0) || variant >= 3) {
-    if (plm_launch_gemm_nt_big(variant, A, lda, B, ldb, (uint16_t*)C, ldc, M, N, K, alpha_dev, nullptr, nullptr, 0, 0, s)) {
+    if (plm_launch_gemm_nt_big(variant, A, lda, B, ldb, (uint16_t*)C, ldc, M, N, K, alpha_dev, nullptr, nullptr, 0, 0, workspace,
+                               workspace_bytes, s)) {
       PLM_CHECK_LAUNCH("plm_gemm_bf16_nt (big tile)");
       return PLM_OK;
     }
@@ -349,9 +350,15 @@ extern "C" int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_
   return PLM_OK;
 }
 
+extern "C" int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                   int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
+                                   void* stream) {
+  return plm_gemm_bf16_nt_ws(A, lda, B, ldb, C, ldc, M, N, K, c_dtype, accumulate, alpha_dev, variant, nullptr, 0, stream);
+}
+
 extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                                 int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream) {
-  return plm_gemm_bf16_nt_ex(A, lda, B, ldb, C, ldc, M, N, K, c_dtype, accumulate, alpha_dev, 0, stream);
+  return plm_gemm_bf16_nt_ws(A, lda, B, ldb, C, ldc, M, N, K, c_dtype, accumulate, alpha_dev, 0, nullptr, 0, stream);
 }
 
 // w_qkv projection with RoPE: qkv[M, 3*nh*hd] = x W^T, then the q | k column blocks are rotated (row m = position m % T).
@@ -366,7 +373,8 @@ extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t*
   hipStream_t s = (hipStream_t)stream;
   const bool fused_ok = getenv("PLM_NO_FUSED_ROPE") == nullptr && (K % GBK == 0) && (ldq % 8 == 0) && ldx % 8 == 0 && ldw % 8 == 0 &&
                         (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(QKV)) & 15) == 0);
-  if (fused_ok && plm_launch_gemm_nt_big(0, X, ldx, W, ldw, QKV, ldq, M, N, K, nullptr, rope_cos, rope_sin, (int)T, (int)(2 * nh * hd), s)) {
+  if (fused_ok &&
+      plm_launch_gemm_nt_big(0, X, ldx, W, ldw, QKV, ldq, M, N, K, nullptr, rope_cos, rope_sin, (int)T, (int)(2 * nh * hd), nullptr, 0, s)) {
     PLM_CHECK_LAUNCH("plm_qkv_rope_bf16 (fused epilogue)");
     return PLM_OK;
   }

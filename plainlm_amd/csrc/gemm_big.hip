@@ -80,6 +80,19 @@ struct RopeArgs {
   int T;
   int cols;
 };
+// Hybrid work items: the tiles of the first `rfull` tile rows take the whole contraction and write bf16 C (whole
+// rounds of the persistent grid); the K-tiles of the remaining tile rows form ONE stream (tile-major, then k) that is
+// cut into `nchunks` equal runs of `L` K-tiles, one run per workgroup ("stream-K" for the last, partial round).  A run
+// may cross a tile boundary, so it is executed as up to ceil(L/nkt)+1 PIECES; every piece writes raw fp32
+// accumulators to slabs[sidx][row - rfull*BM][N] with sidx = chunk - first chunk touching that tile, and
+// nt_streamk_reduce_kernel sums a tile's pieces.  nchunks = 0 is the plain schedule.  384 tiles on 256 CUs: 2 rounds
+// become 1 + ~0.52.
+struct HybridArgs {
+  int rfull;
+  int nchunks;
+  int L;
+  float* slabs;
+};
 
 // ONEBAR: all four half-tiles of the next K-tile are issued at the top of the current one and the quadrants run
 // back-to-back with a single s_waitcnt vmcnt(0) + barrier per K-tile (the compiler is then free to interleave the
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
-                                                             RopeArgs rope) {
+                                                             RopeArgs rope, HybridArgs hyb) {
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   static_assert(WM * WN == 8 && TN == 64 && (TM == 128 || TM == 64), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
@@ -108,26 +121,56 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int ntiles = tiles_m * tiles_n;
-  const int nk = K / 64;
+  const int n_full = hyb.rfull * tiles_n;
+  const int nkt = K / 64;
+  const int g_total = (tiles_m - hyb.rfull) * tiles_n * nkt;  // K-tiles in the stream-K remainder
+  const int ntiles = n_full + hyb.nchunks;                     // work items
   char* epi = smem + 2 * STAGE + wave * 4096;
 
-  auto coords = [&](int tile, int& m0, int& n0) {
-    const int group_size = BIG_GROUP_M * tiles_n;
-    const int group = tile / group_size;
-    const int first_m = group * BIG_GROUP_M;
-    const int gm = min(tiles_m - first_m, BIG_GROUP_M);
-    const int in_group = tile - group * group_size;
-    m0 = (first_m + in_group % gm) * BM;
-    n0 = (in_group / gm) * BN;
+  // A cursor walks this workgroup's PIECES: item (stride gridDim.x), and inside a chunk item the stream position.
+  struct Cur {
+    int item, g, gend;
+  };
+  auto cur_init = [&](Cur& c, int item) {
+    c.item = item;
+    c.g = c.gend = 0;
+    if (item >= n_full && item < ntiles) {
+      c.g = (item - n_full) * hyb.L;
+      c.gend = min(g_total, c.g + hyb.L);
+    }
+  };
+  // the piece under the cursor (tile origin, K range, slab index; sidx = -1: whole-K tile written to C); advances
+  auto take = [&](Cur& c, int& m0, int& n0, int& kbeg, int& kend, int& sidx) {
+    if (c.item < n_full) {
+      const int group_size = BIG_GROUP_M * tiles_n;
+      const int group = c.item / group_size;
+      const int first_m = group * BIG_GROUP_M;
+      const int gm = min(hyb.rfull - first_m, BIG_GROUP_M);
+      const int in_group = c.item - group * group_size;
+      m0 = (first_m + in_group % gm) * BM;
+      n0 = (in_group / gm) * BN;
+      kbeg = 0;
+      kend = K;
+      sidx = -1;
+      cur_init(c, c.item + gridDim.x);
+    } else {
+      const int t = c.g / nkt;
+      const int k0 = c.g - t * nkt;
+      const int k1 = min(nkt, k0 + (c.gend - c.g));
+      m0 = (hyb.rfull + t / tiles_n) * BM;
+      n0 = (t % tiles_n) * BN;
+      kbeg = k0 * 64;
+      kend = k1 * 64;
+      sidx = (c.item - n_full) - (t * nkt) / hyb.L;
+      c.g += k1 - k0;
+      if (c.g >= c.gend) cur_init(c, c.item + gridDim.x);
+    }
   };
 
   // ---- source pointers of the item being staged (one K-tile of one output tile) ----
   const uint16_t* pa[2][A_DMA];
   const uint16_t* pb[2][B_DMA];
-  auto set_ptrs = [&](int tile) {
-    int m0, n0;
-    coords(tile, m0, n0);
+  auto set_ptrs = [&](int m0, int n0) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -162,34 +205,49 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 
   const int first = xcd_remap(blockIdx.x, gridDim.x);
   if (first >= ntiles) return;
-  int s_tile = first, s_k = 0;  // next item to stage
-  set_ptrs(s_tile);
-  auto advance_staged = [&]() {
-    s_k += 64;
-    if (s_k >= K) {
-      s_k = 0;
-      s_tile += gridDim.x;
-      if (s_tile < ntiles) set_ptrs(s_tile);
+  // staging side: sc = cursor past the piece being staged, (s_k, s_kend) = next K-tile / end of that piece
+  Cur sc;
+  cur_init(sc, first);
+  int s_k = 0, s_kend = 0;
+  bool s_valid = false;  // workgroup-uniform: there is a K-tile left to stage
+  auto open_piece = [&]() {
+    s_valid = sc.item < ntiles;
+    if (s_valid) {
+      int m0, n0, sp_;
+      take(sc, m0, n0, s_k, s_kend, sp_);
+      set_ptrs(m0, n0);
     }
   };
+  auto advance_staged = [&]() {
+    s_k += 64;
+    if (s_k >= s_kend) open_piece();
+  };
+  open_piece();
 
   // read alpha and make the compiler consume it NOW: an ordinary global load still "pending" in hipcc's own
   // bookkeeping would make it emit a draining s_waitcnt vmcnt(0) at the first use inside the tile loop
   float alpha = alpha_dev ? *alpha_dev : 1.f;
   asm volatile("; alpha pinned" : "+v"(alpha));
 
-  // prologue: the first item entirely, into stage 0
-  issue_a(0, smem, s_k);
-  issue_b(0, smem, s_k);
-  issue_b(1, smem, s_k);
-  issue_a(1, smem, s_k);
-  advance_staged();
+  // prologue: the first K-tile entirely, into stage 0
+  {
+    issue_a(0, smem, s_k);
+    issue_b(0, smem, s_k);
+    issue_b(1, smem, s_k);
+    issue_a(1, smem, s_k);
+    advance_staged();
+  }
   wait_vm<0>();
   phase_barrier();
   if (STAG && (wm & 1)) phase_barrier();  // odd wave group runs one barrier behind
 
   int st = 0;
-  for (int tile = first; tile < ntiles; tile += gridDim.x) {
+  Cur cc;
+  cur_init(cc, first);
+  while (cc.item < ntiles) {
+    int m0, n0, kbeg, kend, split;
+    take(cc, m0, n0, kbeg, kend, split);
+    const int nk = (kend - kbeg) / 64;
     f32x16_t acc[2 * AF][2];
 #pragma unroll
     for (int i = 0; i < 2 * AF; ++i)
@@ -199,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
-      const bool more = s_tile < ntiles;  // workgroup-uniform
+      const bool more = s_valid;  // workgroup-uniform
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[4], b1[4];
@@ -291,9 +349,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       st ^= 1;
     }
 
+    if (split >= 0) {
+      // ---- partial piece: raw fp32 accumulators into slab[sidx] (lane owns a row, 4 consecutive columns) ----
+      const int mrem = M - hyb.rfull * BM;
+      float* slab = hyb.slabs + ((int64_t)split * mrem - (int64_t)hyb.rfull * BM) * N;
+#pragma unroll
+      for (int mf = 0; mf < 2 * AF; ++mf) {
+        const int gm = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32 + l31;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int gn = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;
+            if (gn >= N) continue;
+            const f32x4_t v = {acc[mf][bh][4 * g + 0], acc[mf][bh][4 * g + 1], acc[mf][bh][4 * g + 2], acc[mf][bh][4 * g + 3]};
+            *reinterpret_cast<f32x4_t*>(slab + (int64_t)gm * N + gn) = v;
+          }
+        }
+      }
+      continue;
+    }
     // ---- epilogue: 32-row x 64-col pieces through this wave's private 4 KiB scratch ----
-    int m0, n0;
-    coords(tile, m0, n0);
 #pragma unroll
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
@@ -599,6 +676,72 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
                      accumulate, alpha_dev, tm, tn);
 }
 
+// C[row0 + r][c] = bf16(alpha * sum of the pieces of (r, c)'s tile) for the stream-K rows of a hybrid NT GEMM.
+// The pieces of remainder tile t come from chunks floor(t*nkt/L) .. floor(((t+1)*nkt-1)/L), slab index = chunk - first.
+__global__ __launch_bounds__(256) void nt_streamk_reduce_kernel(const float* __restrict__ ws, uint16_t* __restrict__ C, int64_t ldc, int rows,
+                                                                int N, int tiles_n, int nkt, int L, int nchunks,
+                                                                const float* __restrict__ alpha_dev) {
+  const float alpha = alpha_dev ? *alpha_dev : 1.f;
+  const int nq = N >> 3;
+  const int64_t nv = (int64_t)rows * nq;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    const int64_t row = i / nq;
+    const int col = (int)(i - row * nq) * 8;
+    const int t = (int)(row >> 8) * tiles_n + (col >> 8);
+    const int cf = (t * nkt) / L;
+    const int cl = min(((t + 1) * nkt - 1) / L, nchunks - 1);
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(ws + row * N + col);
+    f32x4_t b = *reinterpret_cast<const f32x4_t*>(ws + row * N + col + 4);
+    for (int k = 1; k <= cl - cf; ++k) {
+      a += *reinterpret_cast<const f32x4_t*>(ws + ((int64_t)k * rows + row) * N + col);
+      b += *reinterpret_cast<const f32x4_t*>(ws + ((int64_t)k * rows + row) * N + col + 4);
+    }
+    u32x4_t o = {pack_bf2(a[0] * alpha, a[1] * alpha), pack_bf2(a[2] * alpha, a[3] * alpha), pack_bf2(b[0] * alpha, b[1] * alpha),
+                 pack_bf2(b[2] * alpha, b[3] * alpha)};
+    *reinterpret_cast<u32x4_t*>(C + row * ldc + col) = o;
+  }
+}
+
+// Hybrid plan for the 256x256 NT kernel: whole-K tiles for the full rounds, stream-K over the remaining tile rows.
+// Returns false when the plain schedules are at least as good (or the shape does not qualify).
+struct NtHybridPlan {
+  int rfull, nchunks, L, nslabs;
+};
+bool plm_nt_hybrid_plan(int64_t M, int64_t N, int64_t K, NtHybridPlan* p) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (getenv("PLM_NT_NO_HYBRID") != nullptr) return false;
+  const char* mk = getenv("PLM_NT_HYBRID_MIN_K");  // tests / A-B runs lower the thresholds
+  const int64_t min_k = mk ? atoll(mk) : 8192, min_l = mk ? 2 : 8;  // measured (profiles/r01_kbench_run18*): the fp32 slab traffic (~40 us) only pays off for long K
+  if (K % 64 != 0 || N % 8 != 0 || M < 2048 || N < 256 || K < min_k) return false;
+  const int slots = persistent_slots();
+  const int64_t R = plm_cdiv(M, 256), Cn = plm_cdiv(N, 256), tiles = R * Cn, nkt = K / 64;
+  if (tiles <= slots) return false;                          // single partial round: nothing to balance
+  if (round_efficiency(tiles, slots) >= 0.9) return false;  // plain 256x256 is already well packed
+  const int64_t rf = ((tiles / slots) * slots) / Cn;        // whole tile rows inside the full rounds
+  const int64_t rem = (R - rf) * Cn;
+  if (rem <= 0 || rf <= 0) return false;
+  const int64_t total = rem * nkt;
+  const int64_t L = plm_cdiv(total, slots);
+  if (L < min_l || L * 10 > nkt * 9) return false;  // too short to amortise a prologue / no round saved
+  p->rfull = (int)rf;
+  p->L = (int)L;
+  p->nchunks = (int)plm_cdiv(total, L);
+  p->nslabs = (int)((nkt - 1) / L + 2);
+  return true;
+}
+
+extern "C" size_t plm_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  NtHybridPlan p;
+  if (M <= 0 || N <= 0 || K <= 0 || !plm_nt_hybrid_plan(M, N, K, &p)) return 0;
+  return (size_t)p.nslabs * (size_t)(M - (int64_t)p.rfull * 256) * (size_t)N * sizeof(float);
+}
+
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
 // variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered,
@@ -608,7 +751,7 @@ void plm_launch_gemm_nt_w4(int slots, const uint16_t* A, int64_t lda, const uint
 
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
-                            int rope_T, int rope_cols, hipStream_t s) {
+                            int rope_T, int rope_cols, void* workspace, size_t workspace_bytes, hipStream_t s) {
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -622,8 +765,36 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
   // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
   // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
-  if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
   const dim3 block(512);
+  const RopeArgs rope{rope_cos, rope_sin, rope_T, rope_cols};
+  const HybridArgs hyb{tm, 0, 1, nullptr};  // plain schedule
+  // hybrid whole-K + stream-K schedule on 256x256 tiles (automatic choice only; needs the caller's fp32 workspace)
+  if (variant == 0 && !rope_cos && workspace) {
+    NtHybridPlan p;
+    if (plm_nt_hybrid_plan(M, N, K, &p)) {
+      const int64_t rem_rows = M - (int64_t)p.rfull * 256;
+      const size_t need = (size_t)p.nslabs * (size_t)rem_rows * (size_t)N * sizeof(float);
+      if (workspace_bytes >= need) {
+        const HybridArgs h{p.rfull, p.nchunks, p.L, (float*)workspace};
+        const int nitems = p.rfull * tn256 + p.nchunks;
+        const dim3 g2(nitems < slots ? nitems : slots);
+        const bool ob = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
+        if (ob)
+          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                             (int)K, alpha_dev, tm, tn256, rope, h);
+        else
+          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                             (int)K, alpha_dev, tm, tn256, rope, h);
+        const int64_t nv = rem_rows * (N / 8);
+        int64_t rb = plm_cdiv(nv, 256);
+        if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL(nt_streamk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)workspace,
+                           C + (int64_t)p.rfull * 256 * ldc, ldc, (int)rem_rows, (int)N, tn256, (int)(K / 64), p.L, p.nchunks, alpha_dev);
+        return true;
+      }
+    }
+  }
+  if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
   if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip)
     plm_launch_gemm_nt_w4(slots, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
     return true;
@@ -636,27 +807,26 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
   const bool onebar = variant >= 7 || (variant == 0 && auto_onebar);
   const int ntiles = tm * (use256 ? tn256 : tn128);
-  const dim3 grid(ntiles < g_num_cus ? ntiles : g_num_cus);
-  const RopeArgs rope{rope_cos, rope_sin, rope_T, rope_cols};
+  const dim3 grid(ntiles < slots ? ntiles : slots);
 #define PLM_NTB(BN_, WM_, WN_, ST_, RP_, TN_)                                                                                          \
   hipLaunchKernelGGL((gemm_nt_big_kernel<256, BN_, WM_, WN_, ST_, RP_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, \
-                     alpha_dev, tm, TN_, rope)
+                     alpha_dev, tm, TN_, rope, hyb)
   if (rope_cos) {  // fused-RoPE epilogue (non-staggered schedules only)
     if (onebar) {
       if (use256)
         hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                           (int)K, alpha_dev, tm, tn256, rope);
+                           (int)K, alpha_dev, tm, tn256, rope, hyb);
       else
         hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                           (int)K, alpha_dev, tm, tn128, rope);
+                           (int)K, alpha_dev, tm, tn128, rope, hyb);
     } else if (use256) PLM_NTB(256, 2, 4, false, true, tn256); else PLM_NTB(128, 4, 2, false, true, tn128);
   } else if (onebar) {
     if (use256)
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                         (int)K, alpha_dev, tm, tn256, rope);
+                         (int)K, alpha_dev, tm, tn256, rope, hyb);
     else
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                         (int)K, alpha_dev, tm, tn128, rope);
+                         (int)K, alpha_dev, tm, tn128, rope, hyb);
   } else if (use256) {
     if (stag) PLM_NTB(256, 2, 4, true, false, tn256); else PLM_NTB(256, 2, 4, false, false, tn256);
   } else {

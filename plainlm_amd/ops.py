@@ -156,6 +156,18 @@ def swiglu_bwd(dout, u):
 
 
 # ---- GEMMs ------------------------------------------------------------------------
+_tn_ws = {}
+
+
+def _tn_workspace(nbytes, device):
+  """One grow-only split-K slab buffer per device (owned by torch's allocator)."""
+  buf = _tn_ws.get(device)
+  if buf is None or buf.numel() < nbytes:
+    buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    _tn_ws[device] = buf
+  return buf
+
+
 def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, variant=0):
   """C[M,N] = alpha * A[M,K] @ B[N,K]^T ; A, B bf16 (row stride may exceed K).
   variant: 0 auto | 1 128x128 register-staged | 2 128x128 LDS-DMA | 3 persistent 256x256 | 4 persistent 256x128."""
@@ -173,22 +185,13 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, varian
   cd = {BF16: 0, F32: 1}[out.dtype]
   if alpha is not None:
     _need(alpha, F32, 'gemm_nt.alpha')
+  lib = _lib.load()
+  nbytes = lib.plm_gemm_nt_workspace_bytes(M, N, K) if (variant == 0 and cd == 0) else 0
+  ws = _tn_workspace(nbytes, A.device) if nbytes else None  # the split-K slab buffer is shared with gemm_tn (same stream)
   with _Timed('gemm_nt', 2.0 * M * N * K):
-    _lib.check(_lib.load().plm_gemm_bf16_nt_ex(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
-                                               int(bool(accumulate)), _p(alpha), int(variant), _stream()), 'plm_gemm_bf16_nt')
+    _lib.check(lib.plm_gemm_bf16_nt_ws(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
+                                       int(bool(accumulate)), _p(alpha), int(variant), _p(ws), nbytes, _stream()), 'plm_gemm_bf16_nt')
   return out
-
-
-_tn_ws = {}
-
-
-def _tn_workspace(nbytes, device):
-  """One grow-only split-K slab buffer per device (owned by torch's allocator)."""
-  buf = _tn_ws.get(device)
-  if buf is None or buf.numel() < nbytes:
-    buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-    _tn_ws[device] = buf
-  return buf
 
 
 def gemm_tn(A, B, out=None, accumulate=False, alpha=None):

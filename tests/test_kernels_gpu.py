@@ -196,6 +196,32 @@ def test_gemm_nt_variants(ops, M, N, K, variant):
   assert (wide[:, N:] == 0).all()
 
 
+@pytest.mark.parametrize('M,N,K', [(32768, 768, 768), (32768, 768, 2048), (32700, 1032, 1024), (32768, 768, 50304), (20480, 1280, 640),
+                                   (32768, 768, 576), (32768, 768, 4096)])
+def test_gemm_nt_hybrid(ops, M, N, K, monkeypatch):
+  """Shapes whose 256x256 tile count is a bad multiple of the CU count take the hybrid whole-K + stream-K schedule
+  (workspace > 0 asserts that): ragged M/N tails inside the stream-K rows, runs that cross tile boundaries, alpha,
+  padded ldc; plus bit-equality with the plain schedule on exactly-representable inputs."""
+  from plainlm_amd import _lib
+  monkeypatch.setenv('PLM_NT_HYBRID_MIN_K', '64')
+  assert _lib.load().plm_gemm_nt_workspace_bytes(M, N, K) > 0, 'shape does not exercise the hybrid schedule'
+  g = torch.Generator(device='cuda').manual_seed(M + N + K)
+  A = bf(torch.randn(M, K, generator=g, device='cuda'))
+  B = bf(torch.randn(N, K, generator=g, device='cuda'))
+  ref = A.float() @ B.float().t()
+  alpha = torch.tensor(0.5, device='cuda')
+  wide = torch.zeros(M, N + 24, dtype=torch.bfloat16, device='cuda')
+  ops.gemm_nt(A, B, out=wide[:, :N], alpha=alpha)
+  close(wide[:, :N].float(), 0.5 * ref, 6e-3, f'gemm_nt hybrid {M}x{N}x{K}')
+  assert (wide[:, N:] == 0).all()
+  del ref, wide
+  Ai = bf(torch.randint(-3, 4, (M, K), generator=g, device='cuda').float())
+  Bi = bf(torch.randint(-3, 4, (N, K), generator=g, device='cuda').float())
+  hyb = ops.gemm_nt(Ai, Bi)
+  plain = ops.gemm_nt(Ai, Bi, variant=3)
+  assert torch.equal(hyb, plain)  # integer inputs: fp32 sums are exact in any order
+
+
 def test_gemm_nt_strided_operand(ops):
   """A is a column block of a wider buffer (the q|k|v and x|z cases)."""
   g = torch.Generator().manual_seed(5)

@@ -11,7 +11,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from plainlm_amd import ops  # noqa: E402
+from plainlm_amd import ops, _lib  # noqa: E402
 
 BF = torch.bfloat16
 
@@ -65,6 +65,10 @@ def main():
       Bm = torch.randn(n, k, device=dev).to(BF)
       out = torch.empty(m, n, device=dev, dtype=BF)
       rec(name, timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
+      if _lib.load().plm_gemm_nt_workspace_bytes(m, n, k) > 0:
+        os.environ['PLM_NT_NO_HYBRID'] = '1'
+        rec(name + ' [no hybrid]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
+        del os.environ['PLM_NT_NO_HYBRID']
       if k % 64 == 0 and a.variants:
         for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (9, 'w4_256x256')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
