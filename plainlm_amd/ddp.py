@@ -46,7 +46,8 @@ class RcclComm:
     self.handle, self.lib = handle, lib
     self.rank, self.world_size = rank, world_size
     if world_size > 1:
-      _lib.check(lib.plm_set_cu_reserve(COMM_CUS), 'plm_set_cu_reserve')
+      from . import ops
+      ops.set_cu_reserve(COMM_CUS)
 
   def allreduce_avg_(self, span, stream):
     _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),

@@ -5,6 +5,7 @@ Every function here launches hand-written gfx950 kernels; none has a torch fallb
 """
 
 import ctypes as C
+import os
 
 import torch
 
@@ -157,6 +158,23 @@ def swiglu_bwd(dout, u):
 
 # ---- GEMMs ------------------------------------------------------------------------
 _tn_ws = {}
+_nt_ws_cache = {}
+
+
+def set_cu_reserve(n):
+  """Leave n CUs out of the persistent GEMM grids (RCCL runs there during backward); plans change, so drop the cache."""
+  _lib.check(_lib.load().plm_set_cu_reserve(int(n)), 'plm_set_cu_reserve')
+  _nt_ws_cache.clear()
+
+
+def _nt_ws_bytes(lib, M, N, K):
+  """Workspace query of the hybrid NT schedule, cached per shape (the plan depends on the shape, the PLM_NT_* environment knobs -
+  part of the key - and the CU reserve, whose setter clears the cache)."""
+  key = (M, N, K, os.environ.get('PLM_NT_NO_HYBRID'), os.environ.get('PLM_NT_HYBRID_MIN_K'))
+  v = _nt_ws_cache.get(key)
+  if v is None:
+    v = _nt_ws_cache[key] = int(lib.plm_gemm_nt_workspace_bytes(M, N, K))
+  return v
 
 
 def _tn_workspace(nbytes, device):
@@ -186,7 +204,7 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, varian
   if alpha is not None:
     _need(alpha, F32, 'gemm_nt.alpha')
   lib = _lib.load()
-  nbytes = lib.plm_gemm_nt_workspace_bytes(M, N, K) if (variant == 0 and cd == 0) else 0
+  nbytes = _nt_ws_bytes(lib, M, N, K) if (variant == 0 and cd == 0) else 0
   ws = _tn_workspace(nbytes, A.device) if nbytes else None  # the split-K slab buffer is shared with gemm_tn (same stream)
   with _Timed('gemm_nt', 2.0 * M * N * K):
     _lib.check(lib.plm_gemm_bf16_nt_ws(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, cd,
