@@ -97,7 +97,11 @@ struct HybridArgs {
 // ONEBAR: all four half-tiles of the next K-tile are issued at the top of the current one and the quadrants run
 // back-to-back with a single s_waitcnt vmcnt(0) + barrier per K-tile (the compiler is then free to interleave the
 // ds_reads of later quadrants with the MFMAs of earlier ones).
-template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false>
+// DEEP (4-phase schedule only): a half-tile slot is refilled as soon as the phase that read it has ended, with the
+// half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups
+// (80 KiB for 256x256) are in flight behind every counted wait instead of two.  Measured (profiles/r01_kbench_run19*):
+// global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deeper queue lets them overlap.
+template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false, bool DEEP = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -115,6 +119,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   constexpr int W_P4 = A_DMA + B_DMA;  // end of phase 4: B1', A1' may stay in flight
   constexpr int W_P1 = 2 * A_DMA;      // end of phase 1: A1', A0'' may stay in flight
   constexpr int W_P2 = A_DMA + B_DMA;  // end of phase 2: A0'', B0'' may stay in flight
+  static_assert(!DEEP || (!STAG && !ONEBAR), "DEEP is a variant of the plain 4-phase schedule");
+  // DEEP: groups younger than the one a wait retires (see the schedule above)
+  constexpr int D_P4 = 2 * A_DMA + 3 * B_DMA;  // end of phase 4 -> A0, B0 of kt+1: B1', A1', A0'', B0'', B1'' in flight
+  constexpr int D_P1 = 3 * A_DMA + 2 * B_DMA;  // end of phase 1 -> B1 of kt: A1, A0', B0', B1', A1' in flight
+  constexpr int D_P2 = 3 * A_DMA + 2 * B_DMA;  // end of phase 2 -> A1 of kt: A0', B0', B1', A1', A0'' in flight
+  // DEEP: the C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
+  // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
+  // of them (vmcnt retires in order, so a plain count would wait for every store).
+  constexpr int NS = 2 * AF * 4;
+  static_assert(!DEEP || D_P1 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -220,8 +234,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       set_ptrs(m0, n0);
     }
   };
+  int s_st = 0;  // DEEP: stage buffer of the K-tile under the staging cursor
   auto advance_staged = [&]() {
     s_k += 64;
+    s_st ^= 1;
     if (s_k >= s_kend) open_piece();
   };
   open_piece();
@@ -239,11 +255,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     issue_a(1, smem, s_k);
     advance_staged();
   }
-  wait_vm<0>();
+  if (DEEP) {  // plus A0, B0, B1 of the second K-tile (its A1 follows in phase 1 of the first)
+    if (s_item < ntiles) {
+      issue_a(0, smem + STAGE, s_k);
+      issue_b(0, smem + STAGE, s_k);
+      issue_b(1, smem + STAGE, s_k);
+      wait_vm<D_P4>();
+    } else {
+      wait_vm<0>();
+    }
+  } else {
+    wait_vm<0>();
+  }
   phase_barrier();
   if (STAG && (wm & 1)) phase_barrier();  // odd wave group runs one barrier behind
 
   int st = 0;
+  bool credit = false;  // DEEP: NS stores of the previous tile's epilogue are still counted by vmcnt
   Cur cc;
   cur_init(cc, first);
   while (cc.item < ntiles) {
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
-      const bool more = s_item < ntiles;  // workgroup-uniform
+      bool more = s_item < ntiles;  // workgroup-uniform: the staging cursor still points at a K-tile
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[4], b1[4];
@@ -270,9 +298,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       auto end_read = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
         if (ONEBAR) return;
-        if (more) wait_vm<W>(); else wait_vm<0>();
-        phase_barrier();
-        if (STAG) __builtin_amdgcn_s_setprio(1);
+        if (!more) wait_vm<0>();
+        else if (DEEP && credit) wait_vm<DEEP ? W + NS : W>();
+        else wait_vm<W>();
+        if (STAG) {  // barrier first: the LDS reads of this section land while the wave waits for the other group
+          asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_setprio(1);
+        } else {
+          phase_barrier();
+        }
       };
       if (ONEBAR && more) {  // the whole next K-tile goes in flight now
         issue_a(0, nxt, s_k);
@@ -283,45 +317,68 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       auto end_mfma = [&]() {
         if (STAG) {
           __builtin_amdgcn_s_setprio(0);
-          phase_barrier();
+          asm volatile("s_barrier" ::: "memory");
         }
       };
       using std::integral_constant;
 
-      // ---- phase 1: quadrant (A0, B0); stage A0 of the next item
-      if (!ONEBAR && more) issue_a(0, nxt, s_k);
+      // ---- phase 1: quadrant (A0, B0); stage A0 of the next item (DEEP: A1 of the next item, then move the cursor on)
+      if (DEEP) {
+        if (more) {
+          issue_a(1, smem + s_st * STAGE, s_k);
+          advance_staged();
+          more = s_item < ntiles;
+        }
+      } else if (!ONEBAR && !STAG && more) {
+        issue_a(0, nxt, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         b0[ks] = frag(cur + OFF_B0, wn * 32 + l31, ks);
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
       }
-      if (STAG) end_read(integral_constant<int, W_P1>{});
+      if (STAG) {
+        if (more) issue_a(0, nxt, s_k);  // behind the reads: their latency hides the DMA issue
+        end_read(integral_constant<int, W_P1>{});
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(b0[ks], a[f][ks], acc[f][0]);
-      if (STAG) end_mfma(); else end_read(integral_constant<int, W_P1>{});
+      if (STAG) end_mfma(); else end_read(integral_constant<int, DEEP ? D_P1 : W_P1>{});
 
-      // ---- phase 2: quadrant (A0, B1); stage B0
-      if (!ONEBAR && more) issue_b(0, nxt, s_k);
+      // ---- phase 2: quadrant (A0, B1); stage B0 (DEEP: A0 two K-tiles ahead, into the slot phase 1 just read)
+      if (DEEP) {
+        if (more) issue_a(0, smem + s_st * STAGE, s_k);
+      } else if (!ONEBAR && !STAG && more) {
+        issue_b(0, nxt, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
-      if (STAG) end_read(integral_constant<int, W_P2>{});
+      if (STAG) {
+        if (more) issue_b(0, nxt, s_k);
+        end_read(integral_constant<int, W_P2>{});
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(b1[ks], a[f][ks], acc[f][1]);
-      if (STAG) end_mfma(); else end_read(integral_constant<int, W_P2>{});
+      if (STAG) end_mfma(); else end_read(integral_constant<int, DEEP ? D_P2 : W_P2>{});
 
-      // ---- phase 3: quadrant (A1, B1); stage B1.  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
-      if (!ONEBAR && more) issue_b(1, nxt, s_k);
+      // ---- phase 3: quadrant (A1, B1); stage B1 (DEEP: B0).  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
+      if (DEEP) {
+        if (more) issue_b(0, smem + s_st * STAGE, s_k);
+      } else if (!ONEBAR && !STAG && more) {
+        issue_b(1, nxt, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A1, wm * AH + f * 32 + l31, ks);
       if (STAG) {
-        phase_barrier();
+        if (more) issue_b(1, nxt, s_k);
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
       }
 #pragma unroll
@@ -330,8 +387,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(b1[ks], a[f][ks], acc[AF + f][1]);
       if (STAG) end_mfma();
 
-      // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1
-      if (!ONEBAR && more) issue_a(1, nxt, s_k);
+      // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1 (DEEP: B1)
+      if (DEEP) {
+        if (more) issue_b(1, smem + s_st * STAGE, s_k);
+      } else if (!ONEBAR && more) {
+        issue_a(1, nxt, s_k);
+      }
       if (STAG) {
         if (more) advance_staged();
         end_read(integral_constant<int, W_P4>{});
@@ -347,9 +408,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         wait_vm<0>();
         phase_barrier();
       } else {
-        if (more) advance_staged();
-        end_read(integral_constant<int, W_P4>{});
+        if (!DEEP && more) advance_staged();
+        end_read(integral_constant<int, DEEP ? D_P4 : W_P4>{});
       }
+      credit = false;
       st ^= 1;
     }
 
@@ -421,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    credit = DEEP && m0 + BM <= M && n0 + BN <= N;  // interior tile: every wave issued exactly NS stores
   }
   if (STAG && !(wm & 1)) phase_barrier();  // balances the extra barrier of the odd group
 }
@@ -767,7 +830,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128);
   const int slots = persistent_slots();
   const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
-  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.92;  // lower intensity
+  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.88;  // lower intensity (measured: 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape)
   // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
   // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
   const dim3 block(512);
@@ -788,7 +851,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
           hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
         else
-          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
         const int64_t nv = rem_rows * (N / 8);
         int64_t rb = plm_cdiv(nv, 256);
@@ -800,6 +863,19 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
     }
   }
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
+  if (variant == 10 || variant == 11) {  // deep-prefetch 4-phase schedule, 256x256 / 256x128
+    const RopeArgs nr{nullptr, nullptr, 0, 0};
+    const int tn_ = variant == 10 ? tn256 : tn128;
+    const int nt_ = tm * tn_;
+    const dim3 g(nt_ < slots ? nt_ : slots);
+    if (variant == 10)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    else
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    return true;
+  }
   if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip)
     plm_launch_gemm_nt_w4(slots, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
     return true;
@@ -810,7 +886,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const bool auto_onebar = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
   const bool use256 = variant == 3 || variant == 5 || variant == 7 || (variant == 0 && e256 >= e128);
   const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
-  const bool onebar = variant >= 7 || (variant == 0 && auto_onebar);
+  const bool onebar = variant == 7 || variant == 8 || (variant == 0 && auto_onebar);
   const int ntiles = tm * (use256 ? tn256 : tn128);
   const dim3 grid(ntiles < slots ? ntiles : slots);
 #define PLM_NTB(BN_, WM_, WN_, ST_, RP_, TN_)                                                                                          \
@@ -833,9 +909,17 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                          (int)K, alpha_dev, tm, tn128, rope, hyb);
   } else if (use256) {
-    if (stag) PLM_NTB(256, 2, 4, true, false, tn256); else PLM_NTB(256, 2, 4, false, false, tn256);
+    if (stag) PLM_NTB(256, 2, 4, true, false, tn256);
+    else if (variant == 0)  // automatic long-K choice: the deep-prefetch form of the 4-phase schedule (2-6 % faster, run 19)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn256, rope, hyb);
+    else PLM_NTB(256, 2, 4, false, false, tn256);
   } else {
-    if (stag) PLM_NTB(128, 4, 2, true, false, tn128); else PLM_NTB(128, 4, 2, false, false, tn128);
+    if (stag) PLM_NTB(128, 4, 2, true, false, tn128);
+    else if (variant == 0)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn128, rope, hyb);
+    else PLM_NTB(128, 4, 2, false, false, tn128);
   }
 #undef PLM_NTB
   return true;

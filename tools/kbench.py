@@ -16,7 +16,7 @@ from plainlm_amd import ops, _lib  # noqa: E402
 BF = torch.bfloat16
 
 
-def timeit(fn, iters, warmup=3):
+def timeit(fn, iters, warmup=12):  # enough launches for clocks / caches to settle (the first rows used to read 4-8 % slow)
   for _ in range(warmup):
     fn()
   torch.cuda.synchronize()
@@ -70,8 +70,9 @@ def main():
         rec(name + ' [no hybrid]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
         del os.environ['PLM_NT_NO_HYBRID']
       if k % 64 == 0 and a.variants:
-        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (9, 'w4_256x256')):
+        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (10, 'deep256x256'), (11, 'deep256x128'), (5, 'stag256x256'), (6, 'stag256x128')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
+        rec(f'{name} [auto again]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
       del A, Bm, out
     for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
                              'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}.items():
