@@ -99,6 +99,27 @@ def cpu_baseline(c, budget_s=28.0):
                     f'at the fastest of 16/32/64/{ncpu} torch threads (= {best_n}) on a {ncpu}-CPU host'}
 
 
+def pmc_traffic(family, config, tokens, n_layers):
+  """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
+  (profiles/r01_pmc_gemm_traffic_run20.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM
+  shape of the 160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the
+  profiler on itself, so the figure is the profile's, averaged over the launches of one step; null for other workloads."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_run20.json')
+  if family not in ('gemm_nt', 'gemm_tn') or config != '160m' or tokens != 32768 or not os.path.exists(path):
+    return {}
+  rows = {r['gemm']: r for r in json.load(open(path))}
+  if family == 'gemm_nt':  # per layer: 4 forward + 4 dX projections (dX out has the out-fwd shape); plus lm_head fwd and dX
+    per_layer = ['nt qkv fwd', 'nt out fwd', 'nt fc1 fwd', 'nt fc2 fwd', 'nt dX qkv', 'nt out fwd', 'nt dX fc1', 'nt dX fc2']
+    once = ['nt head fwd', 'nt dX head']
+  else:
+    per_layer = ['tn dW qkv', 'tn dW out', 'tn dW fc1', 'tn dW fc2']
+    once = ['tn dW head']
+  launches = n_layers * len(per_layer) + len(once)
+  tot = lambda key: n_layers * sum(rows[g][key] for g in per_layer) + sum(rows[g][key] for g in once)
+  return {'traffic': round(tot('traffic_bytes') / launches), 'traffic_unit': 'bytes/launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, Infinity-Cache hits included)',
+          'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': 'profiles/r01_pmc_gemm_traffic_run20.json'}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -234,6 +255,7 @@ def main():
     out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': fams[dom]['TFLOP/s'], 'peak': PEAK_BF16_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': round(fams[dom]['TFLOP/s'] / PEAK_BF16_TFLOPS, 4), 'traffic': None,
                        'families': fams}
+    out['roofline'].update(pmc_traffic(dom, a.config, B * T, c['n_layers']))
 
     # ---- full training step (clip + AdamW) for reference, same data (untimed leg) ----
     if rank == 0 or world > 1:

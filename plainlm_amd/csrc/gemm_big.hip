@@ -500,6 +500,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 // (C = / += alpha*acc); the tiles of the remaining rows are split `splits` ways over K and write raw fp32 partials
 // into slab[split][row - rfull*256][N], summed by splitk_reduce_kernel.  rfull = 0 is plain split-K (small
 // outputs), splits = 1 with no remainder is plain tiling; the hybrid keeps every CU busy for a whole number of rounds.
+// DEEP: see gemm_nt_big_kernel - half-tile slots are refilled two K-tiles ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1
+// of kt+2), five LDS-DMA groups in flight behind every counted wait.
+template <bool DEEP>
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                              int64_t ldc, float* __restrict__ slabs, int M, int N, int K, int kchunk,
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   constexpr int HT = 64 * 256;  // one half-tile: 64 k-rows x 128 cols bf16
   constexpr int STAGE = 4 * HT;
   constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT;
-  constexpr int W_ALL = 4;  // A_DMA = B_DMA = 2  ->  every counted wait allows 4 DMA instructions in flight
+  constexpr int W_ALL = DEEP ? 10 : 4;  // A_DMA = B_DMA = 2: two (DEEP: five) DMA groups stay in flight behind every counted wait
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -592,8 +595,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       s_item += gridDim.x;
     }
   };
+  int s_st = 0;  // DEEP: stage buffer of the K-tile under the staging cursor
   auto advance_staged = [&]() {
     s_k += 64;
+    s_st ^= 1;
     if (s_k >= s_kend) {
       s_item += gridDim.x;
       open_item();
@@ -607,7 +612,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     issue(pa[1], lda, smem + OFF_A1, s_k);
     advance_staged();
   }
-  wait_vm<0>();
+  if (DEEP && s_item < nitems) {  // plus A0, B0, B1 of the second K-tile
+    issue(pa[0], lda, smem + STAGE + OFF_A0, s_k);
+    issue(pb[0], ldb, smem + STAGE + OFF_B0, s_k);
+    issue(pb[1], ldb, smem + STAGE + OFF_B1, s_k);
+    wait_vm<W_ALL>();
+  } else {
+    wait_vm<0>();
+  }
   phase_barrier();
 
   int st = 0;
@@ -624,12 +636,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 
     const int nk = (kend - kbeg) / 64;
     for (int kt = 0; kt < nk; ++kt) {
-      const bool more = s_item < nitems;  // workgroup-uniform
+      bool more = s_item < nitems;  // workgroup-uniform: the staging cursor still points at a K-tile
+      char* sst = smem + s_st * STAGE;
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[4], b1[4];
 
-      if (more) issue(pa[0], lda, nxt + OFF_A0, s_k);
+      if (DEEP) {
+        if (more) {
+          issue(pa[1], lda, sst + OFF_A1, s_k);
+          advance_staged();
+          more = s_item < nitems;
+          sst = smem + s_st * STAGE;
+        }
+      } else if (more) {
+        issue(pa[0], lda, nxt + OFF_A0, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         b0[ks] = tr_frag(cur + OFF_B0, wn * 32, ks);
@@ -643,7 +665,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       if (more) wait_vm<W_ALL>(); else wait_vm<0>();
       phase_barrier();
 
-      if (more) issue(pb[0], ldb, nxt + OFF_B0, s_k);
+      if (more) {
+        if (DEEP) issue(pa[0], lda, sst + OFF_A0, s_k); else issue(pb[0], ldb, nxt + OFF_B0, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(cur + OFF_B1, wn * 32, ks);
 #pragma unroll
@@ -653,7 +677,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       if (more) wait_vm<W_ALL>(); else wait_vm<0>();
       phase_barrier();
 
-      if (more) issue(pb[1], ldb, nxt + OFF_B1, s_k);
+      if (more) {
+        if (DEEP) issue(pb[0], ldb, sst + OFF_B0, s_k); else issue(pb[1], ldb, nxt + OFF_B1, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -663,13 +689,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(a[f][ks], b1[ks], acc[AF + f][1]);
 
-      if (more) issue(pa[1], lda, nxt + OFF_A1, s_k);
+      if (more) {
+        if (DEEP) issue(pb[1], ldb, sst + OFF_B1, s_k); else issue(pa[1], lda, nxt + OFF_A1, s_k);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(a[f][ks], b0[ks], acc[AF + f][0]);
       if (more) {
-        advance_staged();
+        if (!DEEP) advance_staged();
         wait_vm<W_ALL>();
       } else {
         wait_vm<0>();
@@ -740,8 +768,13 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const int nitems = rfull * tn + (tm - rfull) * tn * splits;
   const int slots = persistent_slots();
   const dim3 grid(nitems < slots ? nitems : slots), block(512);
-  hipLaunchKernelGGL(gemm_tn_big_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
-                     accumulate, alpha_dev, tm, tn);
+  static const bool deep = getenv("PLM_TN_DEEP") != nullptr;  // A/B knob: measured equal (run 19), the plain ring stays the default
+  if (!deep)
+    hipLaunchKernelGGL(gemm_tn_big_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
+                       accumulate, alpha_dev, tm, tn);
+  else
+    hipLaunchKernelGGL(gemm_tn_big_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
+                       accumulate, alpha_dev, tm, tn);
 }
 
 // C[row0 + r][c] = bf16(alpha * sum of the pieces of (r, c)'s tile) for the stream-K rows of a hybrid NT GEMM.
