@@ -80,17 +80,24 @@ __device__ __forceinline__ bf16x8_t frag_cols(const char* tile, int db, int rbas
 // masked out by the caller).
 struct TileDma {
   int row[2], coff[2];
-  __device__ __forceinline__ void init(int wave, int lane) {
+  unsigned boff[2];  // byte offset of this lane's 16 bytes inside a full tile, for the row stride given to init()
+  __device__ __forceinline__ void init(int wave, int lane, int64_t ld = 0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       row[i] = (i * 4 + wave) * 8 + (lane >> 3);
       coff[i] = rs_logical_chunk(row[i], lane & 7) * 8;
+      boff[i] = (unsigned)((row[i] * ld + coff[i]) * 2);
     }
   }
   __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       dma16_asm(src + (int64_t)min(row[i], last_row) * ld + coff[i], dst_tile + (i * 4 + wave) * 1024);
+  }
+  // full tile (no row clamp), row stride = the one given to init(): wave-uniform base in SGPRs + constant lane offsets
+  __device__ __forceinline__ void issue_full(char* dst_tile, const uint16_t* src, int wave) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16_saddr_asm(src, boff[i], dst_tile + (i * 4 + wave) * 1024);
   }
 };
 
@@ -173,12 +180,17 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
   if (HAS_DOC) jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
 
   TileDma dma;
-  dma.init(wave, lane);
+  dma.init(wave, lane, ld);
   auto stage = [&](int st, int jt) {
     const int kv0 = jt * KT;
     const uint16_t* src = base + (int64_t)kv0 * ld;
-    dma.issue(smem + st * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
-    dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    if (kv0 + KT <= T) {  // whole tile inside the sequence (always, when T % 64 == 0): no per-lane address arithmetic
+      dma.issue_full(smem + st * 2 * TILE, src + dm, wave);
+      dma.issue_full(smem + st * 2 * TILE + TILE, src + 2 * dm, wave);
+    } else {
+      dma.issue(smem + st * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+      dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    }
   };
 
   // one KV tile: S^T = K Q^T, online softmax (masked or not), O^T += V^T P^T
@@ -351,13 +363,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   f32x16_t dk[2], dv[2];
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
 
-  TileDma dma;
-  dma.init(wave, lane);
+  TileDma dma, dmad;
+  dma.init(wave, lane, ld);
+  dmad.init(wave, lane, dm);
   auto stage = [&](int st, int jq) {
     const int qt0 = jq * QT;
     char* dst = smem + st * STAGE;
-    dma.issue(dst, base + (int64_t)qt0 * ld, ld, T - 1 - qt0, wave);
-    dma.issue(dst + TILE, dobase + (int64_t)qt0 * dm, dm, T - 1 - qt0, wave);
+    if (qt0 + QT <= T) {
+      dma.issue_full(dst, base + (int64_t)qt0 * ld, wave);
+      dmad.issue_full(dst + TILE, dobase + (int64_t)qt0 * dm, wave);
+    } else {
+      dma.issue(dst, base + (int64_t)qt0 * ld, ld, T - 1 - qt0, wave);
+      dma.issue(dst + TILE, dobase + (int64_t)qt0 * dm, dm, T - 1 - qt0, wave);
+    }
     if (wave == 0 && lane < 16) {  // 64 floats = 16 lanes x 16 bytes per statistic (T % 4 == 0 is checked on the host)
       const int q = min(qt0 + lane * 4, T - 4);
       dma16_asm(lrow + q, dst + 2 * TILE);
@@ -518,12 +536,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   zero16(dq[1]);
 
   TileDma dma;
-  dma.init(wave, lane);
+  dma.init(wave, lane, ld);
   auto stage = [&](int st, int jt) {
     const int kv0 = jt * KT;
     const uint16_t* src = base + (int64_t)kv0 * ld;
-    dma.issue(smem + st * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
-    dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    if (kv0 + KT <= T) {
+      dma.issue_full(smem + st * 2 * TILE, src + dm, wave);
+      dma.issue_full(smem + st * 2 * TILE + TILE, src + 2 * dm, wave);
+    } else {
+      dma.issue(smem + st * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+      dma.issue(smem + st * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    }
   };
 
   auto tile_body = [&](int jt, int st, auto mask_tag) {

@@ -123,6 +123,17 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, const void* lds_wave
                : "memory");
 }
 
+// Same LDS-DMA with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane unsigned 32-bit byte
+// offset: no 64-bit VALU arithmetic per instruction when only the base moves between issues.
+__device__ __forceinline__ void dma16_saddr_asm(const void* uniform_base, unsigned lane_byte_off, const void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds_wave_base));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(uniform_base), "s"(dst)
+               : "memory");
+}
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive ids on one XCD
 // (hardware places workgroup b on XCD b % 8) so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
