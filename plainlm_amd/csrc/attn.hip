@@ -221,7 +221,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
           tmax = fmaxf(tmax, s[kb][r]);
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      {
+        float t_lo, t_hi;
+        half_pair(tmax, t_lo, t_hi);
+        tmax = fmaxf(t_lo, t_hi);
+      }
       const float m_new = fmaxf(m, tmax);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp2((m - m_safe) * c2);
@@ -269,7 +273,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
   for (int jt = jt_lo; jt < jt_diag; ++jt, st ^= 1) tile_body(jt, st, std::false_type{});
   for (int jt = jt_diag; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st, std::true_type{});
 
-  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  float l_lo, l_hi;
+  half_pair(lsum, l_lo, l_hi);
+  const float ltot = l_lo + l_hi;
   if (qvalid) {
     const float inv = 1.f / ltot;
     uint16_t* op = out + ((int64_t)b * T + qrow) * dm + h * HD;

@@ -134,6 +134,17 @@ __device__ __forceinline__ void dma16_saddr_asm(const void* uniform_base, unsign
                : "memory");
 }
 
+// Values of lane l and lane l^32 as a pair (lower-half value, upper-half value) in every lane, by one
+// v_permlane32_swap (gfx950): a cross-half reduction without the LDS round trip of ds_bpermute.
+__device__ __forceinline__ void half_pair(float v, float& lo, float& hi) {
+  // inline asm: hipcc's __builtin_amdgcn_permlane32_swap folds its two results into one register when both
+  // operands carry the same value (observed: v_max_f32 v35, v35, v35 after the swap)
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;  // {v[0..31], v[0..31]}
+  hi = b;  // {v[32..63], v[32..63]}
+}
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive ids on one XCD
 // (hardware places workgroup b on XCD b % 8) so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
