@@ -121,17 +121,41 @@ def doc_start_from_lengths(docs_lengths, seq_len):
   return torch.tensor(rows, dtype=torch.int32)
 
 
-def _move_to_device(batch, seq_len, device, intra_doc_masking):
+class _Stager:
+  """Host -> device staging for `_move_to_device`: the token block travels ONCE ([B, T+1] int64, sliced into
+  inputs / targets on the device) through a small ring of persistent pinned buffers, asynchronously on the compute
+  stream.  The reference pins two fresh tensors per micro-step (engine.py:29-30)."""
+
+  def __init__(self, depth=4):
+    self.bufs, self.depth, self.k = {}, depth, 0
+
+  def to_device(self, t, device):
+    if t.is_cuda:
+      return t
+    key = (tuple(t.shape), t.dtype)
+    ring = self.bufs.setdefault(key, [])
+    if len(ring) < self.depth:
+      ring.append((torch.empty(t.shape, dtype=t.dtype).pin_memory(), torch.cuda.Event()))
+    buf, ev = ring[self.k % len(ring)]
+    self.k += 1
+    ev.synchronize()  # the copy that last used this pinned buffer has finished (it was issued `depth` transfers ago)
+    buf.copy_(t)
+    out = buf.to(device, non_blocking=True)
+    ev.record()
+    return out
+
+
+def _move_to_device(batch, seq_len, device, intra_doc_masking, stager=None):
   """engine/engine.py:13-34 with doc_start instead of the [B,T,T] mask."""
   ids = batch['input_ids']
+  doc_start = doc_start_from_lengths(batch['docs_lengths'], seq_len) if intra_doc_masking else None
+  if stager is None:
+    stager = _Stager(depth=1)
+  ids = stager.to_device(ids[:, :seq_len + 1].contiguous(), device)
   inputs = ids[:, :seq_len].contiguous()
   targets = ids[:, 1:seq_len + 1].contiguous()
-  doc_start = doc_start_from_lengths(batch['docs_lengths'], seq_len) if intra_doc_masking else None
-  if not inputs.is_cuda:
-    inputs = inputs.pin_memory().to(device, non_blocking=True)
-    targets = targets.pin_memory().to(device, non_blocking=True)
   if doc_start is not None:
-    doc_start = doc_start.pin_memory().to(device, non_blocking=True)
+    doc_start = stager.to_device(doc_start, device)
   return inputs, targets, doc_start
 
 
@@ -146,6 +170,11 @@ class HipEngine(torch.nn.Module):
     self.dtype = cfg.dtype
     self.intra_doc_masking = getattr(cfg, 'intra_doc_masking', False)
     self.device = device
+    self._stager = _Stager()
+    # 'Train loss is nan' (engine.py:116-117) is raised for micro-step k when step k + nan_check_lag is submitted (or by
+    # check_losses()), so the host never waits for the micro-step it has just enqueued; 0 = the reference's immediate sync
+    self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 2))
+    self._unchecked, self._flag_pool = [], []
     if self.dtype != 'bfloat16':
       raise NotImplementedError(f"dtype '{self.dtype}': the gfx950 kernels implement the bfloat16 flow only")
     if 'cuda' not in str(device):
@@ -182,7 +211,7 @@ class HipEngine(torch.nn.Module):
     self.model.train()
     self.micro_steps += 1
     self.accumulated_samples += 1
-    inputs, targets, doc_start = _move_to_device(batch, self.seq_len, self.device, self.intra_doc_masking)
+    inputs, targets, doc_start = _move_to_device(batch, self.seq_len, self.device, self.intra_doc_masking, self._stager)
 
     last = self.accumulated_samples == self.accumulation_steps
     if self.accumulated_samples == 1:
@@ -192,8 +221,8 @@ class HipEngine(torch.nn.Module):
 
     loss = self.model.loss(inputs, targets, doc_start)
     loss_val = loss.detach()
-    if torch.isnan(loss_val):
-      raise ValueError('Train loss is nan')
+    self._submit_nan_flag(loss_val)
+    self.check_losses(keep=self.nan_check_lag)
     (loss / self.accumulation_steps).backward()
     if self.reducer is not None:
       self.reducer.finish()
@@ -212,12 +241,35 @@ class HipEngine(torch.nn.Module):
         self.scheduler.step()
     return loss_val
 
+  def _submit_nan_flag(self, loss_val):
+    """isnan(loss) -> pinned host byte, copied asynchronously; the event marks the copy.  Reading the flag later waits
+    for that event only (a `.item()` on the device tensor would wait for everything submitted since)."""
+    if len(self._flag_pool) > 0:
+      host, ev = self._flag_pool.pop()
+    else:
+      host, ev = torch.empty((), dtype=torch.bool).pin_memory(), torch.cuda.Event()
+    host.copy_(torch.isnan(loss_val), non_blocking=True)
+    ev.record()
+    self._unchecked.append((host, ev))
+
+  def check_losses(self, keep=0):
+    """Raise the reference's ValueError for every submitted micro-step but the newest `keep`."""
+    while len(self._unchecked) > keep:
+      host, ev = self._unchecked.pop(0)
+      ev.synchronize()
+      bad = bool(host)
+      self._flag_pool.append((host, ev))
+      if bad:
+        self._unchecked.clear()
+        raise ValueError('Train loss is nan')
+
   @torch.no_grad()
   def eval(self, dataloader):
+    self.check_losses()
     self.model.eval()
     total_loss, num_batches = 0.0, 0
     for batch in dataloader:
-      inputs, targets, doc_start = _move_to_device(batch, self.seq_len, self.device, self.intra_doc_masking)
+      inputs, targets, doc_start = _move_to_device(batch, self.seq_len, self.device, self.intra_doc_masking, self._stager)
       loss = self.model.loss(inputs, targets, doc_start)
       if torch.isnan(loss):
         raise ValueError('Validation loss is nan')

@@ -198,6 +198,33 @@ def test_engine_docmask_and_errors(P, mdl):
     P.TorchEngine(model, cfg, 'cpu', None, None)
 
 
+def test_engine_nan_check_and_staging(P, mdl):
+  """engine.py:116-117: a NaN loss raises ValueError - deferred by `nan_check_lag` micro-steps (default 2) so that the host
+  never syncs on the step it has just submitted; `check_losses()` / lag 0 give the reference's immediate behaviour.
+  Also: the pinned staging ring hands over the same tokens as a plain copy."""
+  cfg = _engine_cfg(grad_accumulation_steps=1)
+  model, _ = P.construct_model(cfg)
+  model.load_state_dict(_weights(mdl))
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  tok = mdl['tokens']
+  from plainlm_amd.engine import _move_to_device, _Stager
+  st = _Stager(depth=2)
+  for _ in range(5):  # more transfers than ring slots: buffers are reused
+    ids, tgt, _ds = _move_to_device({'input_ids': tok}, 64, 'cuda', False, st)
+    assert torch.equal(ids.cpu(), tok[:, :64]) and torch.equal(tgt.cpu(), tok[:, 1:65])
+  ok = eng.step({'input_ids': tok})
+  assert torch.isfinite(ok)
+  with torch.no_grad():
+    eng.model.out_norm.weight.fill_(float('nan'))
+  eng.model.invalidate_shadows()
+  eng.step({'input_ids': tok})  # NaN loss submitted, not yet checked
+  with pytest.raises(ValueError, match='Train loss is nan'):
+    eng.check_losses()
+  eng2 = P.TorchEngine(model, _engine_cfg(grad_accumulation_steps=1, nan_check_lag=0), 'cuda', None, None)
+  with pytest.raises(ValueError, match='Train loss is nan'):
+    eng2.step({'input_ids': tok})
+
+
 def test_eval_mean_over_batches(P, mdl):
   cfg = _engine_cfg()
   model, _ = P.construct_model(cfg)

@@ -1,0 +1,47 @@
+"""Throughput of the drop-in engine (`plainlm_amd.TorchEngine.step`, the call train.py:73 makes) on the 160M config:
+host batches in, loss tensor out, clip + AdamW + LR schedule at every window end.  Compares with bench.py's raw
+fwd+bwd figure to show what the engine layer (host->device copy, NaN check sync, optimizer) costs."""
+import argparse
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import plainlm_amd as P  # noqa: E402
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--accum', type=int, default=1)
+  a = ap.parse_args()
+  cfg = SimpleNamespace(model='transformer', vocab_size=50280, d_model=768, expand='8/3', n_layers=12, n_heads=12, mlp_class='glu',
+                        seq_len=1024, tie_embeddings=False, dtype='bfloat16', optim='adamw', fused_optim=True, lr=3e-4, beta1=0.9,
+                        beta2=0.95, weight_decay=0.1, eps=1e-8, scheduler='warmup_cosine', warmup_steps=10, lr_start=0.0, lr_end=1e-5,
+                        lr_end_pct=None, steps_budget=1000, grad_accumulation_steps=a.accum, grad_clip=1.0, intra_doc_masking=False,
+                        resume=False, seed=100, micro_batch_size=32)
+  torch.manual_seed(cfg.seed)
+  model, _ = P.construct_model(cfg)
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  rng = np.random.default_rng(0)
+  batches = [{'input_ids': torch.from_numpy(rng.integers(0, cfg.vocab_size, size=(32, 1025)))} for _ in range(4)]
+  for i in range(4):
+    eng.step(batches[i % 4])
+  torch.cuda.synchronize()
+  if os.environ.get('PLM_SYNC_DEBUG'):
+    torch.cuda.set_sync_debug_mode('warn')
+  t0 = time.perf_counter()
+  for i in range(a.steps * a.accum):
+    loss = eng.step(batches[i % 4])
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  n = a.steps * a.accum
+  print({'engine_ms_per_micro_step': round(1e3 * dt / n, 3), 'tokens_per_s': round(32 * 1024 * n / dt, 1), 'accum': a.accum, 'loss': float(loss)})
+
+
+if __name__ == '__main__':
+  main()
