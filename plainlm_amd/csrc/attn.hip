@@ -425,14 +425,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
-            float p = fast_exp2(s[r] * c2 - L4[e]);
+            float p = fast_exp2(__builtin_fmaf(s[r], c2, -L4[e]));  // explicit fma: hipcc otherwise pairs s*c2 with lse*LOG2E in a v_pk_mul (16 v_mov per block)
             if (MASK) {
               const int qg = qt0 + ql0 + e;
               bool ok = (kvrow <= qg) && (qg < T);
               if (HAS_DOC) ok = ok && (kvrow >= ds4[e]);
               p = ok ? p : 0.f;
             }
-            const float dsv = p * (dp[r] - D4[e]) * scale;
+            const float dsv = p * (dp[r] - D4[e]);  // the 1/sqrt(hd) factor (a power of two: exact) is applied once, to dK, in the epilogue
             pf[r >> 3][r & 7] = f2bf(p);
             dsf[r >> 3][r & 7] = f2bf(dsv);
           }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
         // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
         const float c0 = rcos[kvrow * 32 + d0 / 2], c1 = rcos[kvrow * 32 + d0 / 2 + 1];
         const float s0 = rsin[kvrow * 32 + d0 / 2], s1 = rsin[kvrow * 32 + d0 / 2 + 1];
-        const float a0 = dk[db][4 * g + 0], b0 = dk[db][4 * g + 1], a1 = dk[db][4 * g + 2], b1 = dk[db][4 * g + 3];
+        const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
         bf16x4_t ok;
         ok[0] = f2bf(a0 * c0 + b0 * s0);
         ok[1] = f2bf(b0 * c0 - a0 * s0);
@@ -575,14 +575,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
         bf16x8_t dsf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float p = fast_exp2(s[r] * c2 - Lq);
+          float p = fast_exp2(__builtin_fmaf(s[r], c2, -Lq));
           if (MASK) {
             const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
             bool ok = (kvg <= qrow);
             if (HAS_DOC) ok = ok && (kvg >= dsq);
             p = ok ? p : 0.f;
           }
-          dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq) * scale);
+          dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq));  // x 1/sqrt(hd) once, in the epilogue
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
         const int d0 = db * 32 + 8 * g + 4 * hi;
         const float c0 = rcos[qrow * 32 + d0 / 2], c1 = rcos[qrow * 32 + d0 / 2 + 1];
         const float s0 = rsin[qrow * 32 + d0 / 2], s1 = rsin[qrow * 32 + d0 / 2 + 1];
-        const float a0 = dq[db][4 * g + 0], b0 = dq[db][4 * g + 1], a1 = dq[db][4 * g + 2], b1 = dq[db][4 * g + 3];
+        const float a0 = dq[db][4 * g + 0] * scale, b0 = dq[db][4 * g + 1] * scale, a1 = dq[db][4 * g + 2] * scale, b1 = dq[db][4 * g + 3] * scale;
         bf16x4_t ov;
         ov[0] = f2bf(a0 * c0 + b0 * s0);
         ov[1] = f2bf(b0 * c0 - a0 * s0);
