@@ -108,8 +108,8 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  * rope_cos/sin fp32[T, hd/2] (interleaved-pair convention).  doc_start int32[B,T] or NULL (pure causal):
  * query i attends key j iff doc_start[i] <= j <= i (doc_start non-decreasing in i).
  * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (once per layer; fp32 math, bf16 result).
- * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (natural-log LSE of the
- *               scaled scores).  No transposed / contiguous copies of q, k, v are made anywhere.
+ * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (BASE-2 log-sum-exp of the
+ *               scaled scores, = LSE / ln 2: the form plm_attn_bwd's exp2 consumes; opaque to the caller otherwise).  No transposed / contiguous copies of q, k, v are made anywhere.
  * plm_attn_bwd: same rotated qkv; dqkv bf16[B*T, 3*nh*hd] = gradient w.r.t. the PRE-rotation q, k (the inverse
  *               rotation is applied in the kernels' epilogues) and v; delta fp32[B,nh,T] scratch. */
 int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
         st_bf16x4(op + db * 32 + 8 * g + 4 * hi, v);
       }
     }
-    if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = m * scale + logf(ltot);
+    if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = m * c2 + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
   }
 }
 
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
         for (int g = 0; g < 4; ++g) {
           // this lane's query rows for registers 4g..4g+3 are consecutive: one 16-byte read per statistic
           const int ql0 = qb * 32 + 8 * g + 4 * hi;
-          const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0) * LOG2E;
+          const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0);  // base-2 LSE
           const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
           int ds4[4] = {0, 0, 0, 0};
           if (MASK && HAS_DOC) {
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   float Lq = 0.f, Dq = 0.f;
   int dsq = 0;
   if (qvalid) {
-    Lq = lse[((int64_t)b * nh + h) * T + qrow] * LOG2E;
+    Lq = lse[((int64_t)b * nh + h) * T + qrow];  // base-2 LSE
     Dq = delta[((int64_t)b * nh + h) * T + qrow];
     if (HAS_DOC) dsq = doc_start[(int64_t)b * T + qrow];
   }
