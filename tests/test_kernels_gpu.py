@@ -324,9 +324,15 @@ def test_rope_qk_golden(ops, golden_dir):
   assert (qkv[:, 2 * d:] == 1).all()  # v untouched
 
 
+@pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('B,T,nh,K', [(4, 256, 2, 128), (8, 1024, 12, 768), (3, 100, 1, 64)])
-def test_qkv_projection_with_fused_rope(ops, B, T, nh, K):
-  """Projection + RoPE in the GEMM epilogue (big shapes) or GEMM + in-place pass (small ones) vs the oracle."""
+def test_qkv_projection_with_fused_rope(ops, B, T, nh, K, fused, monkeypatch):
+  """Projection + RoPE: GEMM + in-place pass (default) and, with PLM_FUSED_ROPE=1, the rotation in the GEMM epilogue
+  (big shapes; small ones still take the two-kernel path) vs the oracle."""
+  if fused:
+    monkeypatch.setenv('PLM_FUSED_ROPE', '1')
+  else:
+    monkeypatch.delenv('PLM_FUSED_ROPE', raising=False)
   g = torch.Generator().manual_seed(B * T + nh)
   d = nh * 64
   x = bf(torch.randn(B * T, K, generator=g))
