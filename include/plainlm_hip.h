@@ -45,6 +45,13 @@ int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_
  * bwd: dW[ids[m],:] += dout[m,:]        (atomic fp32 adds; dW must be initialised) */
 int plm_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t M, int64_t d, int64_t V, void* stream);
 int plm_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t M, int64_t d, int64_t V, void* stream);
+/* Deterministic variant without atomics: stable radix sort of the ids, then every vocabulary row is written exactly once as
+ * the sum of its tokens' rows in increasing token order (rows without tokens: zeros when accumulate == 0, untouched
+ * otherwise).  Needs M <= 65536 and V < 65536 and a workspace of plm_embed_bwd_workspace_bytes(M, V) bytes (0 = shape not
+ * supported, use plm_embed_bwd).  With accumulate == 0 dW does not have to be cleared first. */
+size_t plm_embed_bwd_workspace_bytes(int64_t M, int64_t V);
+int plm_embed_bwd_sorted(const int64_t* ids, const float* dout, float* dW, int64_t M, int64_t d, int64_t V, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- RMSNorm (+ residual add) (models/components.py:16-28, transformer.py:81-82)
  * fwd:  r = x (+ branch if branch != NULL)          x fp32[M,d], branch bf16[M,d]

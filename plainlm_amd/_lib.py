@@ -29,6 +29,8 @@ SIGNATURES = {
   'plm_cast_f32_bf16_t': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_embed_fwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_embed_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
+  'plm_embed_bwd_workspace_bytes': (_SZ, [_I64, _I64]),
+  'plm_embed_bwd_sorted': (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P, _SZ, _P]),
   'plm_rmsnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
   'plm_rmsnorm_bwd_blocks': (_I64, [_I64]),
   'plm_rmsnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),

@@ -110,6 +110,167 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deterministic embedding backward (no atomics on the gradient): a stable LSD radix sort of the token ids (two passes of
+// 8-bit digits over 1024-token blocks: per-block histogram -> one-block scan -> stable scatter; M <= 65536 tokens and
+// V < 65536 so that (id, token index) packs into 32 bits), segment bounds per vocabulary row, then one wave per row adds
+// its tokens' gradient rows in increasing token order and writes the row ONCE (zeros for rows without tokens, so the
+// caller does not have to clear dW first).  The sort moves 128 KiB; its cost is the ten dependent launches (~45 us).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void embed_keys_kernel(const int64_t* __restrict__ ids, unsigned* __restrict__ buf, int M, int V) {
+  const int e = blockIdx.x * 1024 + threadIdx.x;
+  if (e >= M) return;
+  const int64_t id = ids[e];
+  const unsigned key = (id < 0 || id >= V) ? (unsigned)V : (unsigned)id;  // out-of-range ids sort behind every row and are ignored
+  buf[e] = (key << 16) | (unsigned)e;
+}
+
+// hist[digit * nb + block] = number of elements of `block` with that digit
+__global__ __launch_bounds__(1024) void embed_hist_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ hist, int M, int shift) {
+  __shared__ unsigned cnt[256];
+  const int t = threadIdx.x, e = blockIdx.x * 1024 + t;
+  if (t < 256) cnt[t] = 0;
+  __syncthreads();
+  if (e < M) atomicAdd(&cnt[(src[e] >> shift) & 255], 1u);  // integer counts: order-independent
+  __syncthreads();
+  if (t < 256) hist[t * gridDim.x + blockIdx.x] = cnt[t];
+}
+
+// in-place exclusive scan of n <= 16384 counters (digit-major, block-minor = the order of a stable sort)
+__global__ __launch_bounds__(1024) void embed_scan_kernel(unsigned* __restrict__ hist, int n) {
+  __shared__ unsigned wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned loc[16], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    loc[j] = (t * 16 + j < n) ? hist[t * 16 + j] : 0u;
+    sum += loc[j];
+  }
+  unsigned incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned base = incl - sum;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (t * 16 + j < n) hist[t * 16 + j] = base;
+    base += loc[j];
+  }
+}
+
+// stable scatter: position = scanned base of (digit, block) + elements of the same digit earlier in the block
+__global__ __launch_bounds__(1024) void embed_scatter_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                             const unsigned* __restrict__ base, int M, int shift) {
+  __shared__ unsigned wcnt[16 * 256];  // [wave][digit]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, e = blockIdx.x * 1024 + t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wcnt[t * 4 + j] = 0;
+  const bool valid = e < M;
+  const unsigned v = valid ? src[e] : 0u;
+  const unsigned d = (v >> shift) & 255;
+  unsigned long long mask = __ballot(valid);  // lanes of this wave holding the same digit
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const bool on = (d >> bit) & 1;
+    const unsigned long long bal = __ballot(on);
+    mask &= on ? bal : ~bal;
+  }
+  const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (valid && rank == 0) wcnt[wave * 256 + d] = (unsigned)__popcll(mask);
+  __syncthreads();
+  if (t < 256) {
+    unsigned run = base[t * gridDim.x + blockIdx.x];
+    for (int w = 0; w < 16; ++w) {
+      const unsigned c = wcnt[w * 256 + t];
+      wcnt[w * 256 + t] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  if (valid) dst[wcnt[wave * 256 + d] + rank] = v;
+}
+
+__global__ __launch_bounds__(1024) void embed_bounds_kernel(const unsigned* __restrict__ sorted, int* __restrict__ seg_lo,
+                                                            int* __restrict__ seg_hi, int M) {
+  const int e = blockIdx.x * 1024 + threadIdx.x;
+  if (e >= M) return;
+  const unsigned k = sorted[e] >> 16;
+  if (e == 0 || (sorted[e - 1] >> 16) != k) seg_lo[k] = e;
+  if (e == M - 1 || (sorted[e + 1] >> 16) != k) seg_hi[k] = e + 1;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const unsigned* __restrict__ sorted, const int* __restrict__ seg_lo,
+                                                               const int* __restrict__ seg_hi, const float* __restrict__ dout,
+                                                               float* __restrict__ dW, int d, int V, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int lo = seg_lo[v], hi = seg_hi[v];
+  if (hi <= lo && accumulate) return;  // nothing to add
+  float* dst = dW + (int64_t)v * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) acc = *reinterpret_cast<const f32x4_t*>(dst + c);
+    for (int p = lo; p < hi; ++p) {
+      const int tok = (int)(sorted[p] & 0xffffu);
+      acc += *reinterpret_cast<const f32x4_t*>(dout + (int64_t)tok * d + c);
+    }
+    *reinterpret_cast<f32x4_t*>(dst + c) = acc;
+  }
+}
+
+extern "C" size_t plm_embed_bwd_workspace_bytes(int64_t M, int64_t V) {
+  if (M <= 0 || V <= 0 || M > 65536 || V >= 65536) return 0;  // 0: use plm_embed_bwd (atomic scatter-add)
+  const int64_t nb = plm_cdiv(M, 1024);
+  return (size_t)(2 * M + 2 * (V + 1) + 256 * nb) * 4;
+}
+
+extern "C" int plm_embed_bwd_sorted(const int64_t* ids, const float* dout, float* dW, int64_t M, int64_t d, int64_t V, int accumulate,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  PLM_REQUIRE(ids && dout && dW && workspace, "plm_embed_bwd_sorted: null pointer");
+  PLM_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && V > 0, "plm_embed_bwd_sorted: bad shape M=%ld d=%ld V=%ld", (long)M, (long)d, (long)V);
+  const size_t need = plm_embed_bwd_workspace_bytes(M, V);
+  PLM_REQUIRE(need != 0, "plm_embed_bwd_sorted: needs M <= 65536 and V < 65536 (M=%ld V=%ld); use plm_embed_bwd", (long)M, (long)V);
+  PLM_REQUIRE(workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "plm_embed_bwd_sorted: workspace of %zu bytes (16-byte aligned) required, %zu given", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (int)plm_cdiv(M, 1024);
+  unsigned* buf0 = (unsigned*)workspace;
+  unsigned* buf1 = buf0 + M;
+  int* seg_lo = (int*)(buf1 + M);
+  int* seg_hi = seg_lo + (V + 1);
+  unsigned* hist = (unsigned*)(seg_hi + (V + 1));
+  if (hipMemsetAsync(seg_lo, 0, (size_t)2 * (V + 1) * 4, s) != hipSuccess) {
+    plm_set_error("plm_embed_bwd_sorted: hipMemsetAsync failed");
+    return PLM_E_HIP;
+  }
+  const dim3 grid((unsigned)nb), block(1024);
+  hipLaunchKernelGGL(embed_keys_kernel, grid, block, 0, s, ids, buf0, (int)M, (int)V);
+  unsigned* src = buf0;
+  unsigned* dst = buf1;
+  const int passes = V < 256 ? 1 : 2;  // keys are 0..V (V = the out-of-range sentinel)
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 16 + 8 * pass;
+    hipLaunchKernelGGL(embed_hist_kernel, grid, block, 0, s, src, hist, (int)M, shift);
+    hipLaunchKernelGGL(embed_scan_kernel, dim3(1), block, 0, s, hist, 256 * nb);
+    hipLaunchKernelGGL(embed_scatter_kernel, grid, block, 0, s, src, dst, hist, (int)M, shift);
+    unsigned* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  hipLaunchKernelGGL(embed_bounds_kernel, grid, block, 0, s, src, seg_lo, seg_hi, (int)M);
+  hipLaunchKernelGGL(embed_bwd_sorted_kernel, dim3((unsigned)plm_cdiv(V, 4)), dim3(256), 0, s, src, seg_lo, seg_hi, dout, dW, (int)d, (int)V,
+                     accumulate);
+  PLM_CHECK_LAUNCH("plm_embed_bwd_sorted");
+  return PLM_OK;
+}
+
 extern "C" int plm_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t M, int64_t d, int64_t V, void* stream) {
   PLM_REQUIRE(ids && W && out, "plm_embed_fwd: null pointer");
   PLM_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && V > 0, "plm_embed_fwd: bad shape M=%ld d=%ld V=%ld", (long)M, (long)d, (long)V);

@@ -88,7 +88,8 @@ class QKVRopeFn(torch.autograd.Function):
 
 
 class EmbedFn(torch.autograd.Function):
-  """nn.Embedding (transformer.py:94,110): fp32 row gather; backward = atomic scatter-add."""
+  """nn.Embedding (transformer.py:94,110): fp32 row gather; backward = sort-based deterministic segment sum (atomic
+  scatter-add only for shapes beyond 65536 tokens / ids)."""
 
   @staticmethod
   def forward(ctx, ids, weight, emb):
@@ -104,13 +105,17 @@ class EmbedFn(torch.autograd.Function):
     g = g.contiguous()
     sink, p = emb.sink, emb.weight
     if sink is not None and sink.active_for(p):
-      if sink.first_write(p):
-        p.main_grad.zero_()
-      ops.embed_bwd(ids, g, p.main_grad)
+      first = sink.first_write(p)
+      if not ops.embed_bwd_sorted(ids, g, p.main_grad, accumulate=not first):  # sort-based, no atomics, writes every row
+        if first:
+          p.main_grad.zero_()
+        ops.embed_bwd(ids, g, p.main_grad)
       sink.ready(p)
       return None, None, None
-    dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=g.device)
-    ops.embed_bwd(ids, g, dw)
+    dw = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
+    if not ops.embed_bwd_sorted(ids, g, dw, accumulate=False):
+      dw.zero_()
+      ops.embed_bwd(ids, g, dw)
     return None, dw, None
 
 

@@ -102,6 +102,29 @@ def embed_bwd(ids, dout, dW):
   return dW
 
 
+_embed_ws = {}
+
+
+def embed_bwd_sorted(ids, dout, dW, accumulate):
+  """dW[v] (+)= sum of dout rows of the tokens with id v, in token order, without atomics (bit-reproducible); with
+  accumulate=False every row of dW is written (zeros for unused ids).  Returns False when the shape is not supported
+  (M > 65536 tokens or V >= 65536) - the caller then falls back to embed_bwd."""
+  ids = ids.reshape(-1)
+  _need(ids, torch.int64, 'embed_bwd_sorted.ids')
+  _need(dout, F32, 'embed_bwd_sorted.dout', 2)
+  _need(dW, F32, 'embed_bwd_sorted.dW', 2)
+  lib = _lib.load()
+  nbytes = lib.plm_embed_bwd_workspace_bytes(ids.numel(), dW.shape[0])
+  if nbytes == 0:
+    return False
+  ws = _embed_ws.get(dout.device)
+  if ws is None or ws.numel() < nbytes:
+    ws = _embed_ws[dout.device] = torch.empty(nbytes, dtype=torch.uint8, device=dout.device)
+  _lib.check(lib.plm_embed_bwd_sorted(_p(ids), _p(dout), _p(dW), ids.numel(), dW.shape[1], dW.shape[0], int(bool(accumulate)),
+                                      _p(ws), nbytes, _stream()), 'plm_embed_bwd_sorted')
+  return True
+
+
 # ---- rmsnorm --------------------------------------------------------------------
 def rmsnorm_fwd(x, w, eps, branch=None, write_xout=False):
   """returns (xout fp32 or None, y bf16, rstd fp32).  r = x + branch; y = bf16(r * rstd * w)."""

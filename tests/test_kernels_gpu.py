@@ -89,6 +89,37 @@ def test_embedding_fwd_bwd_repeated_ids(ops, golden_dir):
   close(dW, torch.from_numpy(z['emb_dw']), 1e-6, 'embedding bwd (golden)')
 
 
+@pytest.mark.parametrize('M,V,d', [(32768, 50280, 768), (4096, 256, 128), (1000, 65535, 64), (65536, 512, 256), (7, 3, 8)])
+def test_embedding_bwd_sorted(ops, M, V, d):
+  """Sort-based embedding backward: equals index_add (fp64 reference), ignores out-of-range ids, writes zeros into unused
+  rows when overwriting, adds onto dW when accumulating, and is bit-reproducible (no atomics) - heavy duplicates included."""
+  g = torch.Generator().manual_seed(M + V)
+  ids = torch.randint(0, V, (M,), generator=g)
+  ids[: M // 4] = ids[0]                       # one very frequent token
+  if M > 5:
+    ids[5] = -1
+    ids[M - 1] = V + 3                         # ignored
+  dout = torch.randn(M, d, generator=g)
+  ok = (ids >= 0) & (ids < V)
+  ref = torch.zeros(V, d, dtype=torch.float64).index_add_(0, ids[ok], dout[ok].double())
+  dW = torch.full((V, d), 7.0, device='cuda')  # stale contents must be overwritten
+  assert ops.embed_bwd_sorted(ids.cuda(), dout.cuda(), dW, accumulate=False)
+  err = (dW.double().cpu() - ref).abs().max().item()
+  assert err <= 1e-6 * max(1.0, ref.abs().max().item()) * max(1, M // 4) ** 0.5, err
+  dW2 = torch.full((V, d), 7.0, device='cuda')
+  ops.embed_bwd_sorted(ids.cuda(), dout.cuda(), dW2, accumulate=False)
+  assert torch.equal(dW, dW2)                  # deterministic
+  acc = torch.ones(V, d, device='cuda')
+  ops.embed_bwd_sorted(ids.cuda(), dout.cuda(), acc, accumulate=True)
+  err = (acc.double().cpu() - (ref + 1)).abs().max().item()
+  assert err <= 1e-6 * max(1.0, ref.abs().max().item()) * max(1, M // 4) ** 0.5, err
+
+
+def test_embedding_bwd_sorted_unsupported_shapes(ops):
+  ids = torch.zeros(8, dtype=torch.int64, device='cuda')
+  assert ops.embed_bwd_sorted(ids, torch.zeros(8, 8, device='cuda'), torch.zeros(70000, 8, device='cuda'), accumulate=False) is False
+
+
 # --------------------------------------------------------------------------------------
 # RMSNorm
 # --------------------------------------------------------------------------------------

@@ -119,7 +119,8 @@ def main():
     W = torch.randn(V, d, device=dev)
     rec('embed fwd', timeit(lambda: ops.embed_fwd(ids, W), a.iters), bytes_=8.0 * M * d + 8.0 * M)
     dW = torch.zeros(V, d, device=dev)
-    rec('embed bwd', timeit(lambda: ops.embed_bwd(ids, x, dW), a.iters), bytes_=12.0 * M * d)
+    rec('embed bwd (atomic)', timeit(lambda: ops.embed_bwd(ids, x, dW), a.iters), bytes_=12.0 * M * d)
+    rec('embed bwd (sorted, writes all of dW)', timeit(lambda: ops.embed_bwd_sorted(ids, x, dW, False), a.iters), bytes_=4.0 * M * d + 4.0 * V * d)
     P = torch.randn(2304, 768, device=dev)
     rec('cast+transpose qkv', timeit(lambda: ops.cast_bf16_t(P), a.iters), bytes_=8.0 * P.numel())
     flat = torch.randn(162_183_936, device=dev)
