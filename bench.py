@@ -148,6 +148,8 @@ def main():
     dist.init_process_group(backend='gloo')  # control plane only (barrier, timing max, RCCL id exchange)
 
   from plainlm_amd import ddp, ops
+  if os.environ.get('PLM_CU_RESERVE'):  # single-GPU what-if: the persistent GEMM grids with CUs set aside as in a multi-GPU run
+    ops.set_cu_reserve(int(os.environ['PLM_CU_RESERVE']))
   c = dict(CONFIGS[a.config])
   if a.micro_batch:
     c['micro_batch'] = a.micro_batch

@@ -253,6 +253,25 @@ def test_gemm_nt_hybrid(ops, M, N, K, monkeypatch):
   assert torch.equal(hyb, plain)  # integer inputs: fp32 sums are exact in any order
 
 
+def test_gemms_with_cu_reserve(ops, monkeypatch):
+  """Multi-GPU runs reserve 16 CUs for RCCL (ddp.RcclComm -> ops.set_cu_reserve): the persistent grids shrink to 240
+  workgroups and every plan (tile choice, hybrid stream-K, TN split) is recomputed for that count.  Same answers required."""
+  monkeypatch.setenv('PLM_NT_HYBRID_MIN_K', '64')
+  g = torch.Generator(device='cuda').manual_seed(11)
+  try:
+    ops.set_cu_reserve(16)
+    for M, N, K in [(32768, 768, 2048), (32768, 2304, 768), (8192, 4096, 768), (32700, 1032, 1024), (4096, 50280, 768)]:
+      A = bf(torch.randn(M, K, generator=g, device='cuda'))
+      B = bf(torch.randn(N, K, generator=g, device='cuda'))
+      close(ops.gemm_nt(A, B).float(), A.float() @ B.float().t(), 6e-3, f'gemm_nt with reserve {M}x{N}x{K}')
+    for M, N, K in [(2304, 768, 32768), (768, 768, 8192), (50280, 768, 4096), (4096, 768, 32768)]:
+      A = bf(torch.randn(K, M, generator=g, device='cuda'))
+      B = bf(torch.randn(K, N, generator=g, device='cuda'))
+      close(ops.gemm_tn(A, B), A.float().t() @ B.float(), 2e-5 * math.sqrt(K), f'gemm_tn with reserve {M}x{N}x{K}')
+  finally:
+    ops.set_cu_reserve(0)
+
+
 def test_gemm_nt_strided_operand(ops):
   """A is a column block of a wider buffer (the q|k|v and x|z cases)."""
   g = torch.Generator().manual_seed(5)
