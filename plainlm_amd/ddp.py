@@ -198,7 +198,34 @@ def make_comm(device, backend=None, group=None):
   if backend == 'rccl':
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    return RcclComm(rank, world, idx, store_group=group)
+    if world == 1:
+      return RcclComm(rank, world, idx, store_group=group)
+    # The direct communicator is created collectively; if it fails on ANY rank every rank falls back to torch.distributed's
+    # nccl (= RCCL) backend, so that a box whose RCCL set-up differs from the build machine still trains.
+    comm, err = None, None
+    try:
+      comm = RcclComm(rank, world, idx, store_group=group)
+    except Exception as e:  # noqa: BLE001 - reported below, on every rank
+      err = e
+    if all_ranks_ok(err is None, group):
+      return comm
+    if comm is not None:
+      comm.close()
+    print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl', flush=True)
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
+    from . import ops
+    ops.set_cu_reserve(COMM_CUS)
+    return TorchDistComm(dist.new_group(backend='nccl'))
   if not dist.is_initialized():
     raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")
   return TorchDistComm(group)
+
+
+def all_ranks_ok(ok, group=None):
+  """True iff `ok` is true on every rank (control-plane all-reduce on CPU tensors; works on gloo and nccl groups)."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return bool(ok)
+  dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+  flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+  dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+  return bool(flag.item())

@@ -75,6 +75,9 @@ def _worker(rank, world, port, out_dir):
       assert calls['n'] == 0  # no communication on non-final accumulation micro-steps
     red.finish()
   assert calls['n'] == len(red.buckets)
+  # collective agreement used by make_comm's RCCL -> torch fallback: one failing rank makes every rank fall back
+  assert ddp.all_ranks_ok(True) is True
+  assert ddp.all_ranks_ok(rank != 1) is False
   torch.save({'params': flat_p.clone(), 'grads': flat_g.clone()}, os.path.join(out_dir, f'r{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()
