@@ -105,6 +105,20 @@ int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_t* B, int64
                         int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                         void* workspace, size_t workspace_bytes, void* stream);
 size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* Several tn problems with the SAME contraction length K (the dW GEMMs of one transformer block: engine/engine.py's
+ * backward reaches them one after the other, none of them has a consumer inside backward) as ONE stream-K launch + one
+ * reduce: C_p[M_p, N_p] (+)= alpha_p * A_p[K, M_p]^T B_p[K, N_p].  count <= 8; workspace from the query below. */
+typedef struct plm_tn_problem {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int64_t M, N;
+  int accumulate;
+  const float* alpha_dev;
+} plm_tn_problem;
+size_t plm_gemm_tn_grouped_workspace_bytes(const int64_t* Ms, const int64_t* Ns, int count, int64_t K);
+int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, int64_t K, void* workspace, size_t workspace_bytes,
+                             void* stream);
 int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int accumulate, const float* alpha_dev,
                      void* workspace, size_t workspace_bytes, void* stream);

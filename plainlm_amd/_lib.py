@@ -21,6 +21,12 @@ _I = C.c_int
 _F = C.c_float
 _SZ = C.c_size_t
 
+class TnProblem(C.Structure):
+  """struct plm_tn_problem (include/plainlm_hip.h)."""
+  _fields_ = [('A', _P), ('lda', _I64), ('B', _P), ('ldb', _I64), ('C', _P), ('ldc', _I64), ('M', _I64), ('N', _I64),
+              ('accumulate', _I), ('alpha_dev', _P)]
+
+
 # name -> (restype, argtypes); must cover every function in include/plainlm_hip.h
 SIGNATURES = {
   'plm_version': (_I, []),
@@ -43,6 +49,8 @@ SIGNATURES = {
   'plm_gemm_bf16_nt_ws': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _I, _P, _SZ, _P]),
   'plm_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
   'plm_gemm_bf16_tn': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
+  'plm_gemm_tn_grouped_workspace_bytes': (_SZ, [C.POINTER(_I64), C.POINTER(_I64), _I, _I64]),
+  'plm_gemm_bf16_tn_grouped': (_I, [C.POINTER(TnProblem), _I, _I64, _P, _SZ, _P]),
   'plm_rope_qk': (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_qkv_rope_bf16': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),

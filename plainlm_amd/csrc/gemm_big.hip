@@ -502,12 +502,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 // outputs), splits = 1 with no remainder is plain tiling; the hybrid keeps every CU busy for a whole number of rounds.
 // DEEP: see gemm_nt_big_kernel - half-tile slots are refilled two K-tiles ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1
 // of kt+2), five LDS-DMA groups in flight behind every counted wait.
-template <bool DEEP>
+// GROUPED: up to PLM_TN_GROUP_MAX independent problems with the same contraction length (the dW GEMMs of one transformer
+// block: same token rows, different projections) run as ONE stream-K launch: the K-tiles of all their 256x256 output tiles
+// form one stream cut into `nchunks` equal runs of L K-tiles, one run per workgroup; a run is executed as one piece per
+// tile it touches, every piece writes its raw fp32 accumulators to the dense block ws[(sidx * ntiles + tile)][256][256]
+// (sidx = chunk - first chunk of the tile), tn_grouped_reduce_kernel sums a tile's pieces into C.  Against four
+// separate split-K launches this keeps every CU busy, gives each workgroup a long K run and cuts the slab traffic.
+#define PLM_TN_GROUP_MAX 8
+struct TnGroup {
+  const uint16_t* A[PLM_TN_GROUP_MAX];
+  const uint16_t* B[PLM_TN_GROUP_MAX];
+  int64_t lda[PLM_TN_GROUP_MAX], ldb[PLM_TN_GROUP_MAX];
+  int M[PLM_TN_GROUP_MAX], N[PLM_TN_GROUP_MAX], tiles_n[PLM_TN_GROUP_MAX];
+  int tile_base[PLM_TN_GROUP_MAX + 1];  // first global tile of each problem; [count] = number of tiles
+  int count, nchunks, L;
+  int splits;  // > 0: uniform split-K instead of stream-K (items = splits x tiles, split-major: the workgroups of an XCD share a
+               // split's A / B panels in L2, which the tile-major stream cannot offer); L is then the split length in K-tiles
+};
+
+template <bool DEEP, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                              int64_t ldc, float* __restrict__ slabs, int M, int N, int K, int kchunk,
                                                              int splits, int rfull, int accumulate,
-                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n) {
+                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n, TnGroup grp) {
   constexpr int BM = 256, BN = 256, WN = 4;
   constexpr int TM = 128, TN = 64, AH = 64, AF = 2;
   constexpr int HT = 64 * 256;  // one half-tile: 64 k-rows x 128 cols bf16
@@ -522,11 +540,47 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
   const int n_full = rfull * tiles_n;
   const int n_rem = tiles_m * tiles_n - n_full;
-  const int nitems = n_full + n_rem * splits;
+  const int nkt = K / 64;
+  // GROUPED: item = sub * nchunks + chunk (the launch has exactly nchunks workgroups, so workgroup c meets its own pieces)
+  const int g_sub = GROUPED ? (grp.L + nkt - 2) / nkt + 1 : 0;  // pieces a run can touch
+  const int nitems = GROUPED ? (grp.splits > 0 ? grp.splits * grp.tile_base[grp.count] : g_sub * grp.nchunks) : n_full + n_rem * splits;
+  int c_prob = 0, c_tile = 0;  // GROUPED: problem / global tile of the item coords() looked at last
 
   // split = -1: whole-K tile written to C; split >= 0: partial into slab[split]
   auto coords = [&](int item, int& i0, int& j0, int& kbeg, int& kend, int& split) {
     int tile;
+    if (GROUPED) {
+      int t, lo, hi2;
+      if (grp.splits > 0) {
+        const int ntl = grp.tile_base[grp.count];
+        split = item / ntl;
+        t = item - split * ntl;
+        lo = t * nkt + min(nkt, split * grp.L);
+        hi2 = t * nkt + min(nkt, (split + 1) * grp.L);
+      } else {
+        const int sub = item / grp.nchunks, c = item - sub * grp.nchunks;
+        const int g0 = c * grp.L, g1 = min(grp.tile_base[grp.count] * nkt, g0 + grp.L);
+        t = g0 / nkt + sub;
+        lo = max(g0, t * nkt);
+        hi2 = min(g1, (t + 1) * nkt);
+        split = c - (t * nkt) / grp.L;
+      }
+      kbeg = kend = 0;
+      i0 = j0 = 0;
+      if (hi2 <= lo) return;  // the run does not reach this tile
+      int pidx = 0;
+#pragma unroll
+      for (int q = 1; q < PLM_TN_GROUP_MAX; ++q)
+        if (q < grp.count && t >= grp.tile_base[q]) pidx = q;
+      const int local = t - grp.tile_base[pidx];
+      i0 = (local / grp.tiles_n[pidx]) * BM;
+      j0 = (local % grp.tiles_n[pidx]) * BN;
+      kbeg = (lo - t * nkt) * 64;
+      kend = (hi2 - t * nkt) * 64;
+      c_prob = pidx;
+      c_tile = t;
+      return;
+    }
     if (item < n_full) {
       split = -1;
       tile = item;
@@ -546,9 +600,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   // DMA lane map: instruction q = i*8 + wave covers k-rows q*4 .. q*4+3; lane -> (row, physical 16-byte chunk)
   const uint16_t* pa[2][2];
   const uint16_t* pb[2][2];
+  int64_t s_lda = lda, s_ldb = ldb;  // row strides of the problem being staged
   auto set_ptrs = [&](int item) {
     int i0, j0, kbeg, kend, split;
     coords(item, i0, j0, kbeg, kend, split);
+    const uint16_t* Ap = GROUPED ? grp.A[c_prob] : A;
+    const uint16_t* Bp = GROUPED ? grp.B[c_prob] : B;
+    const int Mp = GROUPED ? grp.M[c_prob] : M, Np = GROUPED ? grp.N[c_prob] : N;
+    if (GROUPED) {
+      s_lda = grp.lda[c_prob];
+      s_ldb = grp.ldb[c_prob];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 8 + wave) * 4 + (lane >> 4);
@@ -559,8 +621,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       for (int h = 0; h < 2; ++h) {
         const int ci = i0 + (c / AH) * TM + h * AH + (c % AH);  // A: wave-row group, half, local column
         const int cj = j0 + (c / 32) * TN + h * 32 + (c % 32);  // B: wave-col group, half, local column
-        pa[h][i] = A + (int64_t)row * lda + min(ci, M - 8);
-        pb[h][i] = B + (int64_t)row * ldb + min(cj, N - 8);
+        pa[h][i] = Ap + (int64_t)row * s_lda + min(ci, Mp - 8);
+        pb[h][i] = Bp + (int64_t)row * s_ldb + min(cj, Np - 8);
       }
     }
   };
@@ -606,16 +668,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   };
   open_item();
   if (s_item < nitems) {
-    issue(pa[0], lda, smem + OFF_A0, s_k);
-    issue(pb[0], ldb, smem + OFF_B0, s_k);
-    issue(pb[1], ldb, smem + OFF_B1, s_k);
-    issue(pa[1], lda, smem + OFF_A1, s_k);
+    issue(pa[0], s_lda, smem + OFF_A0, s_k);
+    issue(pb[0], s_ldb, smem + OFF_B0, s_k);
+    issue(pb[1], s_ldb, smem + OFF_B1, s_k);
+    issue(pa[1], s_lda, smem + OFF_A1, s_k);
     advance_staged();
   }
   if (DEEP && s_item < nitems) {  // plus A0, B0, B1 of the second K-tile
-    issue(pa[0], lda, smem + STAGE + OFF_A0, s_k);
-    issue(pb[0], ldb, smem + STAGE + OFF_B0, s_k);
-    issue(pb[1], ldb, smem + STAGE + OFF_B1, s_k);
+    issue(pa[0], s_lda, smem + STAGE + OFF_A0, s_k);
+    issue(pb[0], s_ldb, smem + STAGE + OFF_B0, s_k);
+    issue(pb[1], s_ldb, smem + STAGE + OFF_B1, s_k);
     wait_vm<W_ALL>();
   } else {
     wait_vm<0>();
@@ -626,6 +688,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   for (int item = first; item < nitems; item += gridDim.x) {
     int i0, j0, kbeg, kend, split;
     coords(item, i0, j0, kbeg, kend, split);
+    if (GROUPED && kend <= kbeg) continue;  // this run has no piece in that tile
+    const int e_tile = c_tile;
     f32x16_t acc[2 * AF][2];
 #pragma unroll
     for (int i = 0; i < 2 * AF; ++i)
@@ -644,13 +708,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 
       if (DEEP) {
         if (more) {
-          issue(pa[1], lda, sst + OFF_A1, s_k);
+          issue(pa[1], s_lda, sst + OFF_A1, s_k);
           advance_staged();
           more = s_item < nitems;
           sst = smem + s_st * STAGE;
         }
       } else if (more) {
-        issue(pa[0], lda, nxt + OFF_A0, s_k);
+        issue(pa[0], s_lda, nxt + OFF_A0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -666,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       phase_barrier();
 
       if (more) {
-        if (DEEP) issue(pa[0], lda, sst + OFF_A0, s_k); else issue(pb[0], ldb, nxt + OFF_B0, s_k);
+        if (DEEP) issue(pa[0], s_lda, sst + OFF_A0, s_k); else issue(pb[0], s_ldb, nxt + OFF_B0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(cur + OFF_B1, wn * 32, ks);
@@ -678,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       phase_barrier();
 
       if (more) {
-        if (DEEP) issue(pb[0], ldb, sst + OFF_B0, s_k); else issue(pb[1], ldb, nxt + OFF_B1, s_k);
+        if (DEEP) issue(pb[0], s_ldb, sst + OFF_B0, s_k); else issue(pb[1], s_ldb, nxt + OFF_B1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -690,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
         for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(a[f][ks], b1[ks], acc[AF + f][1]);
 
       if (more) {
-        if (DEEP) issue(pb[1], ldb, sst + OFF_B1, s_k); else issue(pa[1], lda, nxt + OFF_A1, s_k);
+        if (DEEP) issue(pb[1], s_ldb, sst + OFF_B1, s_k); else issue(pa[1], s_lda, nxt + OFF_A1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -707,6 +771,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     }
 
     // epilogue: D[i][j], lane owns column j = l31, 16 rows per accumulator; 128-byte row segments per half-wave
+    if (GROUPED) {  // raw accumulators into this piece's dense 256x256 block (edge rows / columns hold clamped duplicates: ignored)
+      float* blk = slabs + ((int64_t)split * grp.tile_base[grp.count] + e_tile) * (BM * BN);
+      // one lane offset + a wave-uniform base per store (128 precomputed per-lane addresses spilled to scratch)
+      const unsigned lane_off = (unsigned)(((wm * TM + 4 * hi) * BN + wn * TN + l31) * 4);
+#pragma unroll
+      for (int mf = 0; mf < 2 * AF; ++mf) {
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int roff = ((mf / AF) * AH + (mf % AF) * 32 + (r & 3) + 8 * (r >> 2)) * BN + bh * 32;
+            st_f32_saddr(blk + roff, lane_off, acc[mf][bh][r]);
+          }
+        }
+      }
+      continue;
+    }
     const bool direct = split < 0;  // workgroup-uniform
     const int mrem = M - rfull * BM;
     float* out = direct ? C : slabs + ((int64_t)split * mrem - (int64_t)rfull * BM) * N;
@@ -770,11 +851,148 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const dim3 grid(nitems < slots ? nitems : slots), block(512);
   static const bool deep = getenv("PLM_TN_DEEP") != nullptr;  // A/B knob: measured equal (run 19), the plain ring stays the default
   if (!deep)
-    hipLaunchKernelGGL(gemm_tn_big_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
-                       accumulate, alpha_dev, tm, tn);
+    hipLaunchKernelGGL((gemm_tn_big_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
+                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
   else
-    hipLaunchKernelGGL(gemm_tn_big_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits, rfull,
-                       accumulate, alpha_dev, tm, tn);
+    hipLaunchKernelGGL((gemm_tn_big_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
+                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
+}
+
+// ---- grouped TN (dW of one transformer block in one stream-K launch) ----------------------------------------------
+struct TnGroupOut {
+  float* C[PLM_TN_GROUP_MAX];
+  int64_t ldc[PLM_TN_GROUP_MAX];
+  const float* alpha[PLM_TN_GROUP_MAX];
+  int accumulate[PLM_TN_GROUP_MAX];
+};
+
+// C_p[tile rows/cols] (+)= alpha_p * sum of the tile's pieces; one workgroup per (tile, 16-row group)
+__global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const float* __restrict__ ws, TnGroup grp, TnGroupOut out, int nkt) {
+  const int t = blockIdx.x >> 4, rg = blockIdx.x & 15;
+  int pidx = 0;
+#pragma unroll
+  for (int q = 1; q < PLM_TN_GROUP_MAX; ++q)
+    if (q < grp.count && t >= grp.tile_base[q]) pidx = q;
+  const int local = t - grp.tile_base[pidx];
+  const int i0 = (local / grp.tiles_n[pidx]) * 256, j0 = (local % grp.tiles_n[pidx]) * 256;
+  const int ntiles = grp.tile_base[grp.count];
+  const int cf = grp.splits > 0 ? 0 : (t * nkt) / grp.L;
+  const int cl = grp.splits > 0 ? grp.splits - 1 : min(((t + 1) * nkt - 1) / grp.L, grp.nchunks - 1);
+  const float a = out.alpha[pidx] ? *out.alpha[pidx] : 1.f;
+  const int M = grp.M[pidx], N = grp.N[pidx];
+  float* C = out.C[pidx];
+  const int64_t ldc = out.ldc[pidx];
+  const bool acc = out.accumulate[pidx] != 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = it * 256 + threadIdx.x;      // 16 rows x 64 float4
+    const int r = rg * 16 + (e >> 6), c = (e & 63) * 4;
+    const int row = i0 + r, col = j0 + c;
+    if (row >= M || col >= N) continue;        // N % 8 == 0: the four columns are in range together
+    const float* src = ws + (int64_t)t * 65536 + r * 256 + c;
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
+    for (int k = 1; k <= cl - cf; ++k) v += *reinterpret_cast<const f32x4_t*>(src + (int64_t)k * ntiles * 65536);
+    v *= a;
+    float* dst = C + (int64_t)row * ldc + col;
+    if (acc) v += *reinterpret_cast<const f32x4_t*>(dst);
+    *reinterpret_cast<f32x4_t*>(dst) = v;
+  }
+}
+
+// plan shared by the workspace query and the launch: tiles per problem, run length, slab count
+static bool tn_group_plan(const int64_t* Ms, const int64_t* Ns, int count, int64_t K, TnGroup* g, int* nslabs) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (count < 1 || count > PLM_TN_GROUP_MAX || K % 64 != 0 || K < 64) return false;
+  int base = 0;
+  for (int p = 0; p < count; ++p) {
+    if (Ms[p] < 8 || Ns[p] < 8 || Ms[p] % 8 != 0 || Ns[p] % 8 != 0) return false;
+    g->M[p] = (int)Ms[p];
+    g->N[p] = (int)Ns[p];
+    g->tiles_n[p] = (int)plm_cdiv(Ns[p], 256);
+    g->tile_base[p] = base;
+    base += (int)(plm_cdiv(Ms[p], 256) * plm_cdiv(Ns[p], 256));
+  }
+  g->tile_base[count] = base;
+  g->count = count;
+  const int64_t nkt = K / 64, total = (int64_t)base * nkt;
+  const int slots = persistent_slots();
+  if (getenv("PLM_TN_GROUP_STREAMK") != nullptr) {  // measured slower (run 25): tile-major runs share no operand panels in L2
+    int64_t L = plm_cdiv(total, slots);
+    if (L < 4) L = 4;  // a run this short is all prologue
+    g->L = (int)L;
+    g->nchunks = (int)plm_cdiv(total, L);
+    g->splits = 0;
+    *nslabs = (int)((nkt - 1) / L + 2);
+    return total < (1ll << 30);
+  }
+  // uniform split-K over all problems: the number of splits whose item count fills whole rounds best, >= 8 K-tiles each
+  int best = 1;
+  double best_eff = 0.0;
+  for (int sp = 1; sp <= 32 && nkt / sp >= 8; ++sp) {
+    const double eff = round_efficiency((int64_t)sp * base, slots) * (sp == 1 ? 1.0 : (1.0 - 0.01 * sp));  // mild bias against slab traffic
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = sp;
+    }
+  }
+  g->splits = best;
+  g->L = (int)plm_cdiv(nkt, best);
+  g->nchunks = (int)((int64_t)best * base < slots ? (int64_t)best * base : slots);
+  *nslabs = best;
+  return total < (1ll << 30);
+}
+
+extern "C" size_t plm_gemm_tn_grouped_workspace_bytes(const int64_t* Ms, const int64_t* Ns, int count, int64_t K) {
+  TnGroup g{};
+  int ns = 0;
+  if (!Ms || !Ns || !tn_group_plan(Ms, Ns, count, K, &g, &ns)) return 0;
+  return (size_t)ns * (size_t)g.tile_base[count] * 65536 * sizeof(float);
+}
+
+extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, int64_t K, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  PLM_REQUIRE(probs && workspace, "plm_gemm_bf16_tn_grouped: null pointer");
+  PLM_REQUIRE(count >= 1 && count <= PLM_TN_GROUP_MAX, "plm_gemm_bf16_tn_grouped: count=%d must be 1..%d", count, PLM_TN_GROUP_MAX);
+  int64_t Ms[PLM_TN_GROUP_MAX], Ns[PLM_TN_GROUP_MAX];
+  TnGroup g{};
+  TnGroupOut o{};
+  for (int p = 0; p < count; ++p) {
+    const plm_tn_problem& q = probs[p];
+    PLM_REQUIRE(q.A && q.B && q.C, "plm_gemm_bf16_tn_grouped: null pointer in problem %d", p);
+    PLM_REQUIRE(q.M % 8 == 0 && q.N % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N,
+                "plm_gemm_bf16_tn_grouped: problem %d: M, N, lda, ldb must be multiples of 8, ldc of 4", p);
+    PLM_REQUIRE(((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B) | reinterpret_cast<uintptr_t>(q.C)) & 15) == 0,
+                "plm_gemm_bf16_tn_grouped: problem %d: base pointers must be 16-byte aligned", p);
+    Ms[p] = q.M;
+    Ns[p] = q.N;
+    g.A[p] = q.A;
+    g.B[p] = q.B;
+    g.lda[p] = q.lda;
+    g.ldb[p] = q.ldb;
+    o.C[p] = q.C;
+    o.ldc[p] = q.ldc;
+    o.alpha[p] = q.alpha_dev;
+    o.accumulate[p] = q.accumulate;
+  }
+  int ns = 0;
+  PLM_REQUIRE(tn_group_plan(Ms, Ns, count, K, &g, &ns), "plm_gemm_bf16_tn_grouped: unsupported shapes (K %% 64 == 0, M, N multiples of 8)");
+  const size_t need = (size_t)ns * (size_t)g.tile_base[count] * 65536 * sizeof(float);
+  if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) {
+    plm_set_error("plm_gemm_bf16_tn_grouped: workspace of %zu bytes (16-byte aligned) required, %zu given", need, workspace_bytes);
+    return PLM_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((gemm_tn_big_kernel<false, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
+                     (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
+  hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3((unsigned)(g.tile_base[count] * 16)), dim3(256), 0, s, (const float*)workspace, g, o,
+                     (int)(K / 64));
+  PLM_CHECK_LAUNCH("plm_gemm_bf16_tn_grouped");
+  return PLM_OK;
 }
 
 // C[row0 + r][c] = bf16(alpha * sum of the pieces of (r, c)'s tile) for the stream-K rows of a hybrid NT GEMM.

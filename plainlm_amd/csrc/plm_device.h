@@ -145,6 +145,12 @@ __device__ __forceinline__ void half_pair(float v, float& lo, float& hi) {
   hi = b;  // {v[32..63], v[32..63]}
 }
 
+// 4-byte global store to (wave-uniform 64-bit base in SGPRs) + (per-lane unsigned 32-bit byte offset): no address VGPRs beyond
+// the one lane offset, however many different bases a fully unrolled epilogue uses.
+__device__ __forceinline__ void st_f32_saddr(float* uniform_base, unsigned lane_byte_off, float v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_byte_off), "v"(v), "s"(uniform_base) : "memory");
+}
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive ids on one XCD
 // (hardware places workgroup b on XCD b % 8) so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -8,6 +8,8 @@ buffer through a ``GradSink`` (our engine; enables bucketed RCCL all-reduce that
 overlaps the rest of backward).
 """
 
+import os
+
 import torch
 
 from . import ops
@@ -24,9 +26,31 @@ class GradSink:
     self.enabled = False
     self.written = set()
     self.on_ready = None  # callable(param) or None
+    # Weight gradients of bias-free Linears have no consumer inside backward, so they are queued and issued `dw_group` at a
+    # time (= the four projections of one transformer block) as ONE grouped split-K launch (ops.gemm_tn_grouped): whole
+    # rounds of work items on all CUs and one reduce instead of four (measured -8 % on the block's dW time).
+    self.dw_group = int(os.environ.get('PLM_DW_GROUP', '4'))
+    self.dw_queue = []
 
   def begin_window(self):
+    self.flush_dw()
     self.written.clear()
+
+  def defer_dw(self, dy, x, p):
+    """Queue dW(p) (+)= dy^T x; runs when the group is full or at flush_dw()."""
+    self.dw_queue.append((dy, x, p, not self.first_write(p)))
+    if len(self.dw_queue) >= max(1, self.dw_group):
+      self.flush_dw()
+
+  def flush_dw(self):
+    q, self.dw_queue = self.dw_queue, []
+    if not q:
+      return
+    if len(q) == 1 or not ops.gemm_tn_grouped([(dy, x, p.main_grad, acc, None) for dy, x, p, acc in q]):
+      for dy, x, p, acc in q:
+        ops.gemm_tn(dy, x, out=p.main_grad, accumulate=acc)
+    for _, _, p, _ in q:
+      self.ready(p)
 
   def active_for(self, p):
     return self.enabled and getattr(p, 'main_grad', None) is not None
@@ -62,8 +86,7 @@ class LinearFn(torch.autograd.Function):
     if ctx.needs_input_grad[1]:
       sink, p = lin.sink, lin.weight
       if sink is not None and sink.active_for(p):
-        ops.gemm_tn(dy, x, out=p.main_grad, accumulate=not sink.first_write(p))
-        sink.ready(p)
+        sink.defer_dw(dy, x, p)
       else:
         dw = ops.gemm_tn(dy, x)
     return dx, dw, None
@@ -104,6 +127,8 @@ class EmbedFn(torch.autograd.Function):
     emb = ctx.emb
     g = g.contiguous()
     sink, p = emb.sink, emb.weight
+    if sink is not None:
+      sink.flush_dw()  # the embedding is the first op of forward = the last node of backward: nothing is left queued after it
     if sink is not None and sink.active_for(p):
       first = sink.first_write(p)
       if not ops.embed_bwd_sorted(ids, g, p.main_grad, accumulate=not first):  # sort-based, no atomics, writes every row

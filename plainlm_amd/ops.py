@@ -260,6 +260,40 @@ def gemm_tn(A, B, out=None, accumulate=False, alpha=None):
   return out
 
 
+def gemm_tn_grouped(problems):
+  """Several dW-style GEMMs with the same contraction length as ONE stream-K launch (+ one reduce):
+  problems = [(A[K,M] bf16, B[K,N] bf16, out[M,N] fp32, accumulate, alpha or None), ...] (at most 8);
+  out (+)= alpha * A^T @ B for each.  Returns False when the shapes cannot be grouped (the caller then uses gemm_tn)."""
+  n = len(problems)
+  if n < 1 or n > 8:
+    return False
+  K = problems[0][0].shape[0]
+  arr = (_lib.TnProblem * n)()
+  Ms, Ns = (C.c_int64 * n)(), (C.c_int64 * n)()
+  for i, (A, B, out, accumulate, alpha) in enumerate(problems):
+    for t, nm in ((A, 'A'), (B, 'B')):
+      if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f'gemm_tn_grouped.{nm}: need a 2-D bf16 GPU tensor with unit inner stride')
+    if A.shape[0] != K or B.shape[0] != K:
+      return False
+    M, N = A.shape[1], B.shape[1]
+    if out.dtype != F32 or out.shape != (M, N) or out.stride(1) != 1:
+      raise ValueError('gemm_tn_grouped.out: need fp32 [M, N] with unit inner stride')
+    if alpha is not None:
+      _need(alpha, F32, 'gemm_tn_grouped.alpha')
+    Ms[i], Ns[i] = M, N
+    arr[i] = _lib.TnProblem(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, int(bool(accumulate)), _p(alpha))
+  lib = _lib.load()
+  nbytes = lib.plm_gemm_tn_grouped_workspace_bytes(Ms, Ns, n, K)
+  if nbytes == 0:
+    return False
+  ws = _tn_workspace(nbytes, problems[0][0].device)
+  flops = sum(2.0 * a.shape[1] * b.shape[1] * K for a, b, *_ in problems)
+  with _Timed('gemm_tn', flops):
+    _lib.check(lib.plm_gemm_bf16_tn_grouped(arr, n, K, _p(ws), nbytes, _stream()), 'plm_gemm_bf16_tn_grouped')
+  return True
+
+
 # ---- attention ----------------------------------------------------------------------
 def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
   """Rotate the q and k column blocks of the projection output in place (once per layer)."""

@@ -68,6 +68,8 @@ class FlatAdamW(torch.optim.AdamW):
 
   @torch.no_grad()
   def clip_and_step(self, max_norm=None):
+    if getattr(self.model, 'sink', None) is not None:
+      self.model.sink.flush_dw()  # queued weight-gradient GEMMs (functional.GradSink) must have been issued
     self._step_count += 1
     clip = None
     if max_norm:

@@ -244,6 +244,7 @@ class Transformer(nn.Module):
 
   def attach_grads(self):
     """Expose the flat buffer through ``p.grad`` for optimizers / clipping."""
+    self.sink.flush_dw()
     for p in self.parameters():
       p.grad = p.main_grad
 

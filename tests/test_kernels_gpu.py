@@ -299,6 +299,36 @@ def test_gemm_tn(ops, M, N, K):
   close(acc, 2 + 0.25 * ref, 2e-5 * math.sqrt(K), 'gemm_tn accumulate/alpha')
 
 
+@pytest.mark.parametrize('shapes,K', [
+    ([(768, 2048), (4096, 768), (768, 768), (2304, 768)], 32768),   # the four dW GEMMs of a 160M block (fc2, fc1, w_out, w_qkv)
+    ([(136, 72), (520, 264)], 1024),                                 # ragged tiles
+    ([(256, 256)], 64),                                              # one problem, one K-tile
+    ([(768, 768), (8, 8), (1000, 392)], 4096),
+])
+def test_gemm_tn_grouped(ops, shapes, K):
+  """Grouped stream-K dW launch == the individual GEMMs: every problem, overwrite and accumulate, device alpha; bit-equal to
+  the single-problem kernel on exactly-representable inputs."""
+  g = torch.Generator(device='cuda').manual_seed(K + len(shapes))
+  As = [bf(torch.randn(K, M, generator=g, device='cuda')) for M, _ in shapes]
+  Bs = [bf(torch.randn(K, N, generator=g, device='cuda')) for _, N in shapes]
+  refs = [a.float().t() @ b.float() for a, b in zip(As, Bs)]
+  outs = [torch.full((M, N), 3.0, device='cuda') for M, N in shapes]
+  assert ops.gemm_tn_grouped([(a, b, o, False, None) for a, b, o in zip(As, Bs, outs)])
+  for o, r, (M, N) in zip(outs, refs, shapes):
+    close(o, r, 2e-5 * math.sqrt(K), f'grouped tn {M}x{N}x{K}')
+  alpha = torch.tensor(0.25, device='cuda')
+  outs = [torch.full((M, N), 2.0, device='cuda') for M, N in shapes]
+  assert ops.gemm_tn_grouped([(a, b, o, True, alpha) for a, b, o in zip(As, Bs, outs)])
+  for o, r in zip(outs, refs):
+    close(o, 2 + 0.25 * r, 2e-5 * math.sqrt(K), 'grouped tn accumulate/alpha')
+  Ai = [bf(torch.randint(-3, 4, (K, M), generator=g, device='cuda').float()) for M, _ in shapes]
+  Bi = [bf(torch.randint(-3, 4, (K, N), generator=g, device='cuda').float()) for _, N in shapes]
+  outs = [torch.empty((M, N), device='cuda') for M, N in shapes]
+  assert ops.gemm_tn_grouped([(a, b, o, False, None) for a, b, o in zip(Ai, Bi, outs)])
+  for a, b, o in zip(Ai, Bi, outs):
+    assert torch.equal(o, ops.gemm_tn(a, b))  # small integers: fp32 sums are exact in any order
+
+
 def test_gemm_linearity(ops):
   """Size-independent property at a full-size shape: G(a1+a2) == G(a1)+G(a2) for exactly-representable inputs."""
   g = torch.Generator().manual_seed(9)

@@ -86,6 +86,16 @@ def main():
         del os.environ['PLM_TN_NO_BIG']
       del A, Bm, out
 
+  if want('gemm'):
+    shp = [(d, h), (2 * h, d), (d, d), (3 * d, d)]  # fc2, fc1, w_out, w_qkv: the dW GEMMs of one block
+    As = [torch.randn(M, m, device=dev).to(BF) for m, _ in shp]
+    Bs = [torch.randn(M, n, device=dev).to(BF) for _, n in shp]
+    outs = [torch.zeros(m, n, device=dev) for m, n in shp]
+    fl = sum(2.0 * m * n * M for m, n in shp)
+    rec('tn dW block, 4 launches', timeit(lambda: [ops.gemm_tn(a_, b_, out=o_, accumulate=False) for a_, b_, o_ in zip(As, Bs, outs)], a.iters), flops=fl)
+    rec('tn dW block, grouped stream-K', timeit(lambda: ops.gemm_tn_grouped([(a_, b_, o_, False, None) for a_, b_, o_ in zip(As, Bs, outs)]), a.iters), flops=fl)
+    del As, Bs, outs
+
   if want('attn'):
     from oracle import cpu_ref as O
     cos, sin = (t.to(dev) for t in O.rope_table(64, T))
