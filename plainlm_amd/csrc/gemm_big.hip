@@ -1127,9 +1127,12 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
                          (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
     return true;
   }
-  if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip)
-    plm_launch_gemm_nt_w4(slots, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
-    return true;
+  if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip); whole tiles only, other shapes run as variant 3
+    if (M % 256 == 0 && N % 256 == 0) {
+      plm_launch_gemm_nt_w4(slots, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
+      return true;
+    }
+    variant = 3;
   }
   static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default
   // measured (profiles/r01_kbench_run13_*): one barrier per K-tile is 5-14 % faster for K <= 2304, the 4-phase

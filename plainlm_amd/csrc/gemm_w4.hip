@@ -53,15 +53,30 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const uint16_t* __re
   // needs just (r0, column offset) — no per-instruction pointer array (which hipcc spilled to scratch).
   const int r0 = wave * 8 + (lane >> 3);
   const int coff = ((lane & 7) ^ ((r0 >> 1) & 7)) * 8;
-  int s_m0 = 0, s_n0 = 0;  // origin of the tile being staged
-  auto set_ptrs = [&](int tile) { coords(tile, s_m0, s_n0); };
+  // LDS-DMA addresses = wave-uniform base of the staged tile (SGPRs, moves by 128 bytes per K-tile) + per-lane byte offsets
+  // that only change with the tile (row clamp at the matrix edge): no 64-bit VALU arithmetic in the K loop
+  // (the launcher only takes shapes with M % 256 == 0 and N % 256 == 0, so no row needs clamping: ONE lane offset per operand,
+  // the 32-row step between a wave's pieces goes into the uniform base)
+  const unsigned offa = (unsigned)(((int64_t)r0 * lda + coff) * 2), offb = (unsigned)(((int64_t)r0 * ldb + coff) * 2);
+  const uint16_t* s_a = A;
+  const uint16_t* s_b = B;
+  auto set_ptrs = [&](int tile) {
+    int m0, n0;
+    coords(tile, m0, n0);
+    s_a = A + (int64_t)m0 * lda;
+    s_b = B + (int64_t)n0 * ldb;
+  };
+  // instruction e (0..15) of the next K-tile: even = the A piece e/2, odd = the B piece e/2
+  auto issue_one = [&](char* stage, int k0, int e) {
+    const int i = e >> 1;
+    if (e & 1)
+      dma16_saddr_asm(s_b + (int64_t)(32 * i) * ldb + k0, offb, stage + OPND + (i * 4 + wave) * 1024);
+    else
+      dma16_saddr_asm(s_a + (int64_t)(32 * i) * lda + k0, offa, stage + (i * 4 + wave) * 1024);
+  };
   auto issue = [&](char* stage, int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ra = min(s_m0 + r0 + 32 * i, M - 1), rb = min(s_n0 + r0 + 32 * i, N - 1);
-      dma16_asm(A + (int64_t)ra * lda + (k0 + coff), stage + (i * 4 + wave) * 1024);
-      dma16_asm(B + (int64_t)rb * ldb + (k0 + coff), stage + OPND + (i * 4 + wave) * 1024);
-    }
+    for (int e = 0; e < 16; ++e) issue_one(stage, k0, e);
   };
   struct Frags {
     bf16x8_t a[4], b[4];
@@ -106,24 +121,41 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const uint16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    auto mfma4 = [&](const Frags& f, int i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(f.b[j], f.a[i], acc[i][j]);  // D'[n][m]: lane owns a C row
+    };
+    // 16 MFMAs with one LDS-DMA instruction of the next K-tile behind every second one (an LDS-DMA occupies the wave's issue
+    // port for ~60 cycles = two MFMAs of queued matrix work; four in a row drained the pipe: run 26)
+    auto mfma16_dma = [&](const Frags& f, char* stage, int k0, int e0, bool on) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = mfma32(f.b[j], f.a[i], acc[i][j]);
+          if ((j & 1) && on) issue_one(stage, k0, e0 + i * 2 + (j >> 1));
+        }
+      }
+    };
     auto mfma16 = [&](const Frags& f) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(f.b[j], f.a[i], acc[i][j]);  // D'[n][m]: lane owns a C row
+      for (int i = 0; i < 4; ++i) mfma4(f, i);
     };
 
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = s_tile < ntiles;  // workgroup-uniform: another K-tile (this or a later tile) to stage
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
-      if (more) issue(nxt, s_k);
-      // k-steps 0..2: read the next k-step's fragments, then 16 MFMAs on the current ones
+      // k-step 0: the next k-step's fragments, then 16 MFMAs with the next K-tile's 16 DMA instructions spread between them
       read_frags(fn, cur, 1);
-      mfma16(fc);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this k-step's MFMAs (hipcc sinks them next to their use)
+      const bool dma_on = more;
+      mfma16_dma(fc, nxt, s_k, 0, dma_on);   // k-step 0: instructions 0..7
       read_frags(fc, cur, 2);
-      mfma16(fn);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16_dma(fn, nxt, s_k, 8, dma_on);   // k-step 1: instructions 8..15
       read_frags(fn, cur, 3);
+      __builtin_amdgcn_sched_barrier(0);
       mfma16(fc);
       // K-tile boundary: all reads of `cur` are issued; once they are back and the next stage has landed, everybody
       // may move on — the last 16 MFMAs of this K-tile then run while the next K-tile's first fragments arrive
@@ -131,6 +163,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const uint16_t* __re
       wait_vm<0>();
       phase_barrier();
       if (more) read_frags(fc, nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
       mfma16(fn);
       st ^= 1;
     }
