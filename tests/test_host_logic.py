@@ -158,3 +158,16 @@ def test_bucket_plan():
     assert h0 == l1
   for lo, hi, idxs in b:
     assert (hi - lo) * 4 <= 4 * 700 or len(idxs) == 1
+
+
+def test_bench_metric_definition():
+  """bench.py's work model is SURVEY §8(d)'s: 797 976 576 FLOP per token for the 160M config at T = 1024 (causal-counted
+  attention, fwd+bwd = 3x fwd), 2 460 745 728 for 420M at T = 2048; the committed PMC profile feeds roofline.traffic."""
+  import bench
+  c = bench.CONFIGS['160m']
+  assert bench.flops_per_token(c, 2048) == 797_976_576
+  c = bench.CONFIGS['420m']
+  assert bench.flops_per_token(c, 2816) == 2_460_745_728
+  tr = bench.pmc_traffic('gemm_nt', '160m', 32768, 12)
+  assert tr and tr['traffic'] > tr['algorithmic_bytes'] > 0 and os.path.exists(tr['traffic_source'])
+  assert bench.pmc_traffic('gemm_nt', '420m', 16384, 24) == {}
