@@ -294,30 +294,6 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
 }
 
 // =============================================================================================
-// backward pre-pass: delta[b,h,q] = sum_d dO * O
-// =============================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int64_t BT, int T, int nh) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= BT) return;
-  const int dm = nh * HD;
-  const int64_t b = row / T;
-  const int q = (int)(row - b * T);
-  for (int c = lane; c < dm / 8; c += 64) {
-    const bf16x8_t a = ld_bf16x8(out + row * dm + c * 8);
-    const bf16x8_t g = ld_bf16x8(dout + row * dm + c * 8);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(g[e]);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if ((lane & 7) == 0) delta[(b * nh + (c >> 3)) * T + q] = s;
-  }
-}
-
-// =============================================================================================
 // backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows; q, k rotated)
 // =============================================================================================
 template <bool HAS_DOC>
@@ -495,8 +471,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 // backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows; q, k rotated)
 // =============================================================================================
 template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                             const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta,
                                                              const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                              const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv, int T,
                                                              int nh) {
@@ -523,12 +500,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     qf[ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + d0) : zero_bf16x8();
     dof[ks] = qvalid ? ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + d0) : zero_bf16x8();
   }
+  // delta[q] = sum_d dO[q][d] * O[q][d] (the softmax-backward row term) is computed HERE - the lane pair (hi = 0, 1) of a
+  // query holds all 64 dims of its dO row in the fragments above - and published for the dK/dV kernel, which runs after
+  // this one: no separate pre-pass over O and dO.
   float Lq = 0.f, Dq = 0.f;
   int dsq = 0;
   if (qvalid) {
     Lq = lse[((int64_t)b * nh + h) * T + qrow];  // base-2 LSE
-    Dq = delta[((int64_t)b * nh + h) * T + qrow];
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t o8 = ld_bf16x8(out + ((int64_t)b * T + qrow) * dm + h * HD + ks * 16 + hi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += bf2f(o8[e]) * bf2f(dof[ks][e]);
+    }
+    Dq = part;
     if (HAS_DOC) dsq = doc_start[(int64_t)b * T + qrow];
+  }
+  {
+    float d_lo, d_hi;
+    half_pair(Dq, d_lo, d_hi);  // rows beyond T hold zeros in both halves
+    Dq = d_lo + d_hi;
+    if (qvalid && hi == 0) delta[((int64_t)b * nh + h) * T + qrow] = Dq;
   }
   const int kv_hi = min(T, q0 + 128);
   const int jt_hi = (kv_hi + KT - 1) / KT;
@@ -669,14 +662,14 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   if (int rc = check_attn_shape("plm_attn_bwd", B, T, nh, hd)) return rc;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(256);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)plm_cdiv(B * T, 4)), block, 0, s, out, dout, delta, B * T, (int)T, (int)nh);
+  // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
   const dim3 gkv((unsigned)plm_cdiv(T, 128), (unsigned)nh, (unsigned)B);
   if (doc_start) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
   } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
   }
   PLM_CHECK_LAUNCH("plm_attn_bwd");
   return PLM_OK;
