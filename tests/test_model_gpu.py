@@ -225,6 +225,34 @@ def test_engine_nan_check_and_staging(P, mdl):
     eng2.step({'input_ids': tok})
 
 
+def test_engine_resume_from_reference_style_checkpoint(P, mdl, tmp_path):
+  """a checkpoint with the reference's layout (checkpoint_utils.py:32-38: step / state_dict / optimizer /
+  scheduler / scaler, written by torch.save) resumes on a fresh engine (engine.py:44-47,86-89) and continues exactly like
+  the engine that was never interrupted."""
+  cfg = _engine_cfg(grad_accumulation_steps=2)
+  model, _ = P.construct_model(cfg)
+  model.load_state_dict(_weights(mdl))
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  tok = mdl['tokens']
+  g = torch.Generator().manual_seed(3)
+  batches = [{'input_ids': tok[torch.randperm(tok.shape[0], generator=g)][:1]} for _ in range(8)]
+  for b in batches[:4]:   # two optimizer steps
+    eng.step(b)
+  state = {'step': 2, 'state_dict': eng.model.state_dict(), 'optimizer': eng.optimizer.state_dict(),
+           'scheduler': eng.scheduler.state_dict(), 'scaler': eng.scaler.state_dict()}
+  path = tmp_path / 'ckpt_step_2.pth'
+  torch.save(state, path)
+  cont = [eng.step(b).item() for b in batches[4:]]
+  ckpt = torch.load(path, map_location='cpu', weights_only=False)
+  model2, _ = P.construct_model(cfg)
+  eng2 = P.TorchEngine(model2, _engine_cfg(grad_accumulation_steps=2, resume=True), 'cuda', None, ckpt)
+  assert eng2.micro_steps == 4 and eng2.scheduler.iter == eng.scheduler.iter - 2
+  resumed = [eng2.step(b).item() for b in batches[4:]]
+  np.testing.assert_allclose(resumed, cont, rtol=1e-6)
+  for (n1, p1), (n2, p2) in zip(eng.model.named_parameters(), eng2.model.named_parameters()):
+    assert n1 == n2 and torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), n1
+
+
 def test_eval_mean_over_batches(P, mdl):
   cfg = _engine_cfg()
   model, _ = P.construct_model(cfg)
