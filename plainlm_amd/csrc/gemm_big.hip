@@ -184,36 +184,72 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   };
 
   // ---- source pointers of the item being staged (one K-tile of one output tile) ----
+  // LDS-DMA addresses.  ONEBAR kernels: wave-uniform base of the staged tile (SGPR pair; the K offset is added there) + per-lane
+  // unsigned byte offsets inside the tile's row panel (<= 256 rows) - no 64-bit VALU add, half the address registers per
+  // instruction: 3-5 % faster (run 27).  The 4-phase kernels keep per-lane 64-bit pointers and the builtin (the asm form
+  // measured 1 % slower there: two instructions per phase leave hipcc nothing to schedule around).
+  constexpr bool SADDR = ONEBAR;
+  unsigned oa[2][A_DMA], ob[2][B_DMA];
   const uint16_t* pa[2][A_DMA];
   const uint16_t* pb[2][B_DMA];
+  const uint16_t* s_ab = A;
+  const uint16_t* s_bb = B;
   auto set_ptrs = [&](int m0, int n0) {
+    if (!SADDR) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) {
+          const int r = (i * 8 + wave) * 8 + (lane >> 3);
+          const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+          const int m = min(m0 + (r / AH) * TM + h * AH + (r % AH), M - 1);
+          pa[h][i] = A + (int64_t)m * lda + chunk * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < B_DMA; ++i) {
+          const int r = (i * 8 + wave) * 8 + (lane >> 3);
+          const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+          const int n = min(n0 + (r / 32) * TN + h * 32 + (r % 32), N - 1);
+          pb[h][i] = B + (int64_t)n * ldb + chunk * 8;
+        }
+      }
+      return;
+    }
+    s_ab = A + (int64_t)m0 * lda;
+    s_bb = B + (int64_t)n0 * ldb;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < A_DMA; ++i) {
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int m = min(m0 + (r / AH) * TM + h * AH + (r % AH), M - 1);
-        pa[h][i] = A + (int64_t)m * lda + chunk * 8;
+        const int m = min((r / AH) * TM + h * AH + (r % AH), M - 1 - m0);
+        oa[h][i] = (unsigned)(((int64_t)m * lda + chunk * 8) * 2);
       }
 #pragma unroll
       for (int i = 0; i < B_DMA; ++i) {
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int n = min(n0 + (r / 32) * TN + h * 32 + (r % 32), N - 1);
-        pb[h][i] = B + (int64_t)n * ldb + chunk * 8;
+        const int n = min((r / 32) * TN + h * 32 + (r % 32), N - 1 - n0);
+        ob[h][i] = (unsigned)(((int64_t)n * ldb + chunk * 8) * 2);
       }
     }
   };
   auto issue_a = [&](int h, char* stage, int k0) {
     char* dst = stage + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
-    for (int i = 0; i < A_DMA; ++i) big_dma16(pa[h][i] + k0, dst + (i * 8 + wave) * 1024);
+    for (int i = 0; i < A_DMA; ++i) {
+      if (SADDR) dma16_saddr_asm(s_ab + k0, oa[h][i], dst + (i * 8 + wave) * 1024);
+      else big_dma16(pa[h][i] + k0, dst + (i * 8 + wave) * 1024);
+    }
   };
   auto issue_b = [&](int h, char* stage, int k0) {
     char* dst = stage + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
-    for (int i = 0; i < B_DMA; ++i) big_dma16(pb[h][i] + k0, dst + (i * 8 + wave) * 1024);
+    for (int i = 0; i < B_DMA; ++i) {
+      if (SADDR) dma16_saddr_asm(s_bb + k0, ob[h][i], dst + (i * 8 + wave) * 1024);
+      else big_dma16(pb[h][i] + k0, dst + (i * 8 + wave) * 1024);
+    }
   };
   auto frag = [&](const char* ht, int row, int ks) -> bf16x8_t {
     return *reinterpret_cast<const bf16x8_t*>(ht + big_swz(row, ks * 2 + hi));
