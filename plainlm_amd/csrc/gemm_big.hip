@@ -634,8 +634,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   };
 
   // DMA lane map: instruction q = i*8 + wave covers k-rows q*4 .. q*4+3; lane -> (row, physical 16-byte chunk)
-  const uint16_t* pa[2][2];
-  const uint16_t* pb[2][2];
+  // LDS-DMA addresses = wave-uniform operand base (+ k0 rows, added on the scalar side) + per-lane unsigned byte offsets
+  unsigned pa[2][2], pb[2][2];
+  const uint16_t* s_ap = A;
+  const uint16_t* s_bp = B;
   int64_t s_lda = lda, s_ldb = ldb;  // row strides of the problem being staged
   auto set_ptrs = [&](int item) {
     int i0, j0, kbeg, kend, split;
@@ -647,6 +649,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       s_lda = grp.lda[c_prob];
       s_ldb = grp.ldb[c_prob];
     }
+    s_ap = Ap;
+    s_bp = Bp;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 8 + wave) * 4 + (lane >> 4);
@@ -657,14 +661,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       for (int h = 0; h < 2; ++h) {
         const int ci = i0 + (c / AH) * TM + h * AH + (c % AH);  // A: wave-row group, half, local column
         const int cj = j0 + (c / 32) * TN + h * 32 + (c % 32);  // B: wave-col group, half, local column
-        pa[h][i] = Ap + (int64_t)row * s_lda + min(ci, Mp - 8);
-        pb[h][i] = Bp + (int64_t)row * s_ldb + min(cj, Np - 8);
+        pa[h][i] = (unsigned)(((int64_t)row * s_lda + min(ci, Mp - 8)) * 2);
+        pb[h][i] = (unsigned)(((int64_t)row * s_ldb + min(cj, Np - 8)) * 2);
       }
     }
   };
-  auto issue = [&](const uint16_t* const (&p)[2], int64_t ld, char* dst, int k0) {
+  auto issue = [&](const uint16_t* base, const unsigned (&off)[2], int64_t ld, char* dst, int k0) {
+    const uint16_t* kb = base + (int64_t)k0 * ld;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16_asm(p[i] + (int64_t)k0 * ld, dst + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) dma16_saddr_asm(kb, off[i], dst + (i * 8 + wave) * 1024);
   };
   // operand fragment: 32 logical columns starting at c0 of a half-tile, k-step ks, by two transpose reads
   auto tr_frag = [&](const char* ht, int c0, int ks) -> bf16x8_t {
@@ -704,16 +709,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   };
   open_item();
   if (s_item < nitems) {
-    issue(pa[0], s_lda, smem + OFF_A0, s_k);
-    issue(pb[0], s_ldb, smem + OFF_B0, s_k);
-    issue(pb[1], s_ldb, smem + OFF_B1, s_k);
-    issue(pa[1], s_lda, smem + OFF_A1, s_k);
+    issue(s_ap, pa[0], s_lda, smem + OFF_A0, s_k);
+    issue(s_bp, pb[0], s_ldb, smem + OFF_B0, s_k);
+    issue(s_bp, pb[1], s_ldb, smem + OFF_B1, s_k);
+    issue(s_ap, pa[1], s_lda, smem + OFF_A1, s_k);
     advance_staged();
   }
   if (DEEP && s_item < nitems) {  // plus A0, B0, B1 of the second K-tile
-    issue(pa[0], s_lda, smem + STAGE + OFF_A0, s_k);
-    issue(pb[0], s_ldb, smem + STAGE + OFF_B0, s_k);
-    issue(pb[1], s_ldb, smem + STAGE + OFF_B1, s_k);
+    issue(s_ap, pa[0], s_lda, smem + STAGE + OFF_A0, s_k);
+    issue(s_bp, pb[0], s_ldb, smem + STAGE + OFF_B0, s_k);
+    issue(s_bp, pb[1], s_ldb, smem + STAGE + OFF_B1, s_k);
     wait_vm<W_ALL>();
   } else {
     wait_vm<0>();
@@ -744,13 +749,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 
       if (DEEP) {
         if (more) {
-          issue(pa[1], s_lda, sst + OFF_A1, s_k);
+          issue(s_ap, pa[1], s_lda, sst + OFF_A1, s_k);
           advance_staged();
           more = s_item < nitems;
           sst = smem + s_st * STAGE;
         }
       } else if (more) {
-        issue(pa[0], s_lda, nxt + OFF_A0, s_k);
+        issue(s_ap, pa[0], s_lda, nxt + OFF_A0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       phase_barrier();
 
       if (more) {
-        if (DEEP) issue(pa[0], s_lda, sst + OFF_A0, s_k); else issue(pb[0], s_ldb, nxt + OFF_B0, s_k);
+        if (DEEP) issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k); else issue(s_bp, pb[0], s_ldb, nxt + OFF_B0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(cur + OFF_B1, wn * 32, ks);
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       phase_barrier();
 
       if (more) {
-        if (DEEP) issue(pb[0], s_ldb, sst + OFF_B0, s_k); else issue(pb[1], s_ldb, nxt + OFF_B1, s_k);
+        if (DEEP) issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k); else issue(s_bp, pb[1], s_ldb, nxt + OFF_B1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
         for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(a[f][ks], b1[ks], acc[AF + f][1]);
 
       if (more) {
-        if (DEEP) issue(pb[1], s_ldb, sst + OFF_B1, s_k); else issue(pa[1], s_lda, nxt + OFF_A1, s_k);
+        if (DEEP) issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k); else issue(s_ap, pa[1], s_lda, nxt + OFF_A1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
