@@ -190,31 +190,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // measured 1 % slower there: two instructions per phase leave hipcc nothing to schedule around).
   constexpr bool SADDR = ONEBAR;
   unsigned oa[2][A_DMA], ob[2][B_DMA];
-  const uint16_t* pa[2][A_DMA];
-  const uint16_t* pb[2][B_DMA];
   const uint16_t* s_ab = A;
   const uint16_t* s_bb = B;
   auto set_ptrs = [&](int m0, int n0) {
-    if (!SADDR) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int i = 0; i < A_DMA; ++i) {
-          const int r = (i * 8 + wave) * 8 + (lane >> 3);
-          const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-          const int m = min(m0 + (r / AH) * TM + h * AH + (r % AH), M - 1);
-          pa[h][i] = A + (int64_t)m * lda + chunk * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < B_DMA; ++i) {
-          const int r = (i * 8 + wave) * 8 + (lane >> 3);
-          const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-          const int n = min(n0 + (r / 32) * TN + h * 32 + (r % 32), N - 1);
-          pb[h][i] = B + (int64_t)n * ldb + chunk * 8;
-        }
-      }
-      return;
-    }
     s_ab = A + (int64_t)m0 * lda;
     s_bb = B + (int64_t)n0 * ldb;
 #pragma unroll
@@ -240,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
       if (SADDR) dma16_saddr_asm(s_ab + k0, oa[h][i], dst + (i * 8 + wave) * 1024);
-      else big_dma16(pa[h][i] + k0, dst + (i * 8 + wave) * 1024);
+      else big_dma16(reinterpret_cast<const char*>(s_ab + k0) + oa[h][i], dst + (i * 8 + wave) * 1024);  // uniform base + zext(lane offset)
     }
   };
   auto issue_b = [&](int h, char* stage, int k0) {
@@ -248,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
       if (SADDR) dma16_saddr_asm(s_bb + k0, ob[h][i], dst + (i * 8 + wave) * 1024);
-      else big_dma16(pb[h][i] + k0, dst + (i * 8 + wave) * 1024);
+      else big_dma16(reinterpret_cast<const char*>(s_bb + k0) + ob[h][i], dst + (i * 8 + wave) * 1024);
     }
   };
   auto frag = [&](const char* ht, int row, int ks) -> bf16x8_t {
