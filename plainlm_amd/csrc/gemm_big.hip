@@ -1120,8 +1120,11 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         if (ob)
           hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
-        else
+        else if (getenv("PLM_HYB_DEEP") != nullptr)
           hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                             (int)K, alpha_dev, tm, tn256, rope, h);
+        else  // staggered wave groups: the fastest long-K schedule since the DMA addresses went to the SGPR-base form (run 28)
+          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true, false, false, true, false>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
         const int64_t nv = rem_rows * (N / 8);
         int64_t rb = plm_cdiv(nv, 256);
@@ -1153,10 +1156,19 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
     }
     variant = 3;
   }
-  static const bool auto_stag = getenv("PLM_GEMM_STAG") != nullptr;  // measured 10-15 % slower: off by default
-  // measured (profiles/r01_kbench_run13_*): one barrier per K-tile is 5-14 % faster for K <= 2304, the 4-phase
-  // counted-wait schedule ~10 % faster for K >= 4096
-  const bool auto_onebar = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
+  // Automatic schedule (in-run A/Bs: profiles/r01_kbench_run13*, run19*, run28*):
+  //  * K <= 2304: one barrier per K-tile (5-14 % faster than the phased schedules there);
+  //  * K  > 2304 on 256x256 tiles: the STAGGERED 4-phase schedule - since the LDS-DMA addresses use the SGPR-base form it is the
+  //    fastest long-K kernel (1190 / 1326 TF at 4096^3 / 8192^3, level with the vendor library at 8192^3; lm_head dX hybrid
+  //    2.25 -> 2.02 ms inside the step); where 256x128 tiles fill the rounds better (dX fc1) their deep-prefetch kernel stays:
+  //    inside the real step it measured 210 us against 221 us staggered-256 (the isolated benchmark on N(0,1) data said the
+  //    opposite - these kernels are power-limited and the data matter, so schedules are compared inside bench.py, run 28);
+  //  * very long one-barrier runs (>= 32 rounds of tiles, i.e. the lm_head forward) are 1-2 % faster staggered as well.
+  static const bool no_stag = getenv("PLM_GEMM_NO_STAG") != nullptr;
+  const bool auto_onebar0 = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
+  const bool long_run = (int64_t)tm * tn256 >= 32ll * slots;
+  const bool auto_stag = !no_stag && !rope_cos && e256 >= e128 && (!auto_onebar0 || long_run);
+  const bool auto_onebar = auto_onebar0 && !auto_stag;
   const bool use256 = variant == 3 || variant == 5 || variant == 7 || (variant == 0 && e256 >= e128);
   const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
   const bool onebar = variant == 7 || variant == 8 || (variant == 0 && auto_onebar);
