@@ -1100,7 +1100,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128);
   const int slots = persistent_slots();
   const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
-  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.88;  // lower intensity (measured: 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape)
+  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * (getenv("PLM_E128") ? atof(getenv("PLM_E128")) : 0.88);  // lower intensity (measured: 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape)
   // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
   // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
   const dim3 block(512);
@@ -1116,7 +1116,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         const HybridArgs h{p.rfull, p.nchunks, p.L, (float*)workspace};
         const int nitems = p.rfull * tn256 + p.nchunks;
         const dim3 g2(nitems < slots ? nitems : slots);
-        const bool ob = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
+        const bool ob = K <= 2304 && getenv("PLM_GEMM_ONEBAR") != nullptr;
         if (ob)
           hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
@@ -1156,19 +1156,16 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
     }
     variant = 3;
   }
-  // Automatic schedule (in-run A/Bs: profiles/r01_kbench_run13*, run19*, run28*):
-  //  * K <= 2304: one barrier per K-tile (5-14 % faster than the phased schedules there);
-  //  * K  > 2304 on 256x256 tiles: the STAGGERED 4-phase schedule - since the LDS-DMA addresses use the SGPR-base form it is the
-  //    fastest long-K kernel (1190 / 1326 TF at 4096^3 / 8192^3, level with the vendor library at 8192^3; lm_head dX hybrid
-  //    2.25 -> 2.02 ms inside the step); where 256x128 tiles fill the rounds better (dX fc1) their deep-prefetch kernel stays:
-  //    inside the real step it measured 210 us against 221 us staggered-256 (the isolated benchmark on N(0,1) data said the
-  //    opposite - these kernels are power-limited and the data matter, so schedules are compared inside bench.py, run 28);
-  //  * very long one-barrier runs (>= 32 rounds of tiles, i.e. the lm_head forward) are 1-2 % faster staggered as well.
-  static const bool no_stag = getenv("PLM_GEMM_NO_STAG") != nullptr;
-  const bool auto_onebar0 = K <= 2304 && getenv("PLM_GEMM_NO_ONEBAR") == nullptr;
-  const bool long_run = (int64_t)tm * tn256 >= 32ll * slots;
-  const bool auto_stag = !no_stag && !rope_cos && e256 >= e128 && (!auto_onebar0 || long_run);
-  const bool auto_onebar = auto_onebar0 && !auto_stag;
+  // Automatic schedule, decided INSIDE the training step (bench.py A/Bs of run 28; these kernels are power-limited and the
+  // isolated benchmark on N(0,1) data ranks the schedules differently):
+  //  * the deep-prefetch 4-phase ring for every K and both tile shapes: since the LDS-DMA addresses use the SGPR-base form it
+  //    beats the one-barrier schedule even at K = 768 (828.7 -> 850.6 K tok/s end to end with everything on it);
+  //  * staggered wave groups only in the hybrid lm_head dX launch (2.25 -> 2.02 ms in-step) - as the general long-K choice they
+  //    lost 1 % end to end although they are the fastest variant on square N(0,1) problems (1190 / 1326 TF at 4096^3 / 8192^3);
+  //  * PLM_GEMM_ONEBAR=1 / PLM_GEMM_STAG=1 bring the other schedules back for A/B runs (variants 5-8 select them explicitly).
+  static const bool env_onebar = getenv("PLM_GEMM_ONEBAR") != nullptr, env_stag = getenv("PLM_GEMM_STAG") != nullptr;
+  const bool auto_stag = env_stag && !rope_cos && e256 >= e128;
+  const bool auto_onebar = env_onebar && K <= 2304 && !auto_stag;
   const bool use256 = variant == 3 || variant == 5 || variant == 7 || (variant == 0 && e256 >= e128);
   const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
   const bool onebar = variant == 7 || variant == 8 || (variant == 0 && auto_onebar);
