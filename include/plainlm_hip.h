@@ -155,6 +155,14 @@ int plm_ce_fwd_bwd(uint16_t* logits, const int64_t* targets, float* loss_rows, i
                    float grad_scale, void* stream);
 int plm_mean_f32(const float* x, float* out, int64_t n, void* stream);
 
+/* ---- device-scalar scaling (chunked lm_head + cross-entropy, models/transformer.py:114 + engine/engine.py:111,118)
+ * The chunked head runs its dX / dW GEMMs inside forward, before autograd hands over the upstream gradient g
+ * (engine.py:118 `(loss / accum).backward()`); backward applies g with
+ *   plm_scale_bf16: x[i] <- bf16(x[i] * *alpha_dev)                       (n elements, in place)
+ *   plm_axpy_f32:   out[i] <- (accumulate ? out[i] : 0) + *alpha_dev * x[i]  (alpha_dev NULL = 1.0) */
+int plm_scale_bf16(uint16_t* x, int64_t n, const float* alpha_dev, void* stream);
+int plm_axpy_f32(float* out, const float* x, int64_t n, const float* alpha_dev, int accumulate, void* stream);
+
 /* ---- optimizer tail (engine/engine.py:126-135, optim/init_optim.py:14-21)
  * sumsq: out[0] = sum(x^2) (single-launch deterministic two-stage reduce; scratch >= 4096 floats)
  * adamw: decoupled-weight-decay Adam on a flat fp32 span, matching torch.optim.AdamW:

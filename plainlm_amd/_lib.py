@@ -57,6 +57,8 @@ SIGNATURES = {
   'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P]),
   'plm_mean_f32': (_I, [_P, _P, _I64, _P]),
+  'plm_scale_bf16': (_I, [_P, _I64, _P, _P]),
+  'plm_axpy_f32': (_I, [_P, _P, _I64, _P, _I, _P]),
   'plm_sumsq_f32': (_I, [_P, _I64, _P, _P, _P]),
   'plm_adamw_f32': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
   'plm_set_cu_reserve': (_I, [_I]),

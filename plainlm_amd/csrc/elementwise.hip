@@ -65,6 +65,65 @@ extern "C" int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, voi
   return PLM_OK;
 }
 
+// ===========================================================================
+// device-scalar scaling (chunked lm_head + cross-entropy: the chunk GEMMs run in forward, before autograd knows the
+// upstream gradient g; backward applies g with these two passes)
+// ===========================================================================
+__global__ __launch_bounds__(256) void scale_bf16_kernel(uint16_t* __restrict__ x, int64_t n, const float* __restrict__ alpha_dev) {
+  const float alpha = *alpha_dev;
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(x + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * alpha);
+    st_bf16x8(x + i * 8, v);
+  }
+  const int64_t t = (nvec << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) reinterpret_cast<bf16_t*>(x)[t] = f2bf(bf2f(reinterpret_cast<bf16_t*>(x)[t]) * alpha);
+}
+
+__global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n,
+                                                       const float* __restrict__ alpha_dev, int accumulate) {
+  const float alpha = alpha_dev ? *alpha_dev : 1.f;
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + i * 4);
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) o = *reinterpret_cast<const f32x4_t*>(out + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(alpha, a[j], o[j]);
+    *reinterpret_cast<f32x4_t*>(out + i * 4) = o;
+  }
+  const int64_t t = (nvec << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = __builtin_fmaf(alpha, x[t], accumulate ? out[t] : 0.f);
+}
+
+static int plm_stream_grid(int64_t nvec) {
+  const int64_t work = plm_cdiv(nvec, 256);
+  return (int)(work < 4096 ? (work < 1 ? 1 : work) : 4096);
+}
+
+extern "C" int plm_scale_bf16(uint16_t* x, int64_t n, const float* alpha_dev, void* stream) {
+  PLM_REQUIRE(x && alpha_dev && n >= 0, "plm_scale_bf16: null pointer or negative n");
+  PLM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "plm_scale_bf16: x must be 16-byte aligned");
+  if (n == 0) return PLM_OK;
+  hipLaunchKernelGGL(scale_bf16_kernel, dim3(plm_stream_grid(plm_cdiv(n, 8))), dim3(256), 0, (hipStream_t)stream, x, n, alpha_dev);
+  PLM_CHECK_LAUNCH("plm_scale_bf16");
+  return PLM_OK;
+}
+
+extern "C" int plm_axpy_f32(float* out, const float* x, int64_t n, const float* alpha_dev, int accumulate, void* stream) {
+  PLM_REQUIRE(out && x && n >= 0, "plm_axpy_f32: null pointer or negative n");
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "plm_axpy_f32: pointers must be 16-byte aligned");
+  if (n == 0) return PLM_OK;
+  hipLaunchKernelGGL(axpy_f32_kernel, dim3(plm_stream_grid(plm_cdiv(n, 4))), dim3(256), 0, (hipStream_t)stream, out, x, n, alpha_dev,
+                     accumulate);
+  PLM_CHECK_LAUNCH("plm_axpy_f32");
+  return PLM_OK;
+}
+
 extern "C" int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols,
                                    int64_t ld_t, void* stream) {
   PLM_REQUIRE(src && dst && dst_t, "plm_cast_f32_bf16_t: null pointer");

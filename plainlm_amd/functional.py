@@ -231,34 +231,69 @@ class AttnFn(torch.autograd.Function):
 
 class HeadLossFn(torch.autograd.Function):
   """lm_head + CrossEntropyLoss (transformer.py:114 + engine.py:111) with the logits buffer
-  turned into dlogits in place; returns the mean token loss (fp32 scalar)."""
+  turned into dlogits in place; returns the mean token loss (fp32 scalar).
+
+  chunk_rows > 0: the [M, V] logits are never materialised.  Forward walks the token rows in chunks:
+  logits chunk -> cross-entropy in place (-> dlogits chunk) -> its dX rows and its contribution to dW, all while the
+  chunk is hot; only the un-scaled dX [M, d] and a private fp32 dW [V, d] survive forward, and backward multiplies both
+  by the upstream gradient (3.3 GB -> chunk_rows/M of it at the 160M bench shape)."""
 
   @staticmethod
-  def forward(ctx, y, weight, lin, targets):
-    wb, _ = lin.shadow()
+  def forward(ctx, y, weight, lin, targets, chunk_rows=0):
+    wb, wbt = lin.shadow()
     M, V = y.shape[0], lin.out_features
-    # rows padded to a multiple of 64 columns: 128-byte aligned rows, and dlogits feeds the dX GEMM with K % 64 == 0
-    buf = torch.empty((M, lin.out_pad), dtype=torch.bfloat16, device=y.device)
-    ops.gemm_nt(y, wb, out=buf[:, :V])
-    rows = ops.ce_fwd_bwd_(buf, targets, 1.0 / M, V=V)
-    ctx.save_for_backward(y, buf)
     ctx.lin = lin
-    return ops.mean(rows)
+    ctx.chunked = bool(chunk_rows) and 0 < chunk_rows < M
+    if not ctx.chunked:
+      # rows padded to a multiple of 64 columns: 128-byte aligned rows, and dlogits feeds the dX GEMM with K % 64 == 0
+      buf = torch.empty((M, lin.out_pad), dtype=torch.bfloat16, device=y.device)
+      ops.gemm_nt(y, wb, out=buf[:, :V])
+      rows = ops.ce_fwd_bwd_(buf, targets, 1.0 / M, V=V)
+      ctx.save_for_backward(y, buf)
+      return ops.mean(rows)
+    buf = torch.empty((chunk_rows, lin.out_pad), dtype=torch.bfloat16, device=y.device)
+    need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]  # False under no_grad (evaluation): loss only
+    dy = torch.empty_like(y) if need else None
+    dw = torch.empty((V, lin.in_features), dtype=torch.float32, device=y.device) if need else None
+    rows = []
+    for c0 in range(0, M, chunk_rows):
+      n = min(chunk_rows, M - c0)
+      b, yc = buf[:n], y[c0:c0 + n]
+      ops.gemm_nt(yc, wb, out=b[:, :V])
+      rows.append(ops.ce_fwd_bwd_(b, targets[c0:c0 + n], 1.0 / M, V=V))
+      if need:
+        ops.gemm_nt(b, wbt, out=dy[c0:c0 + n])
+        ops.gemm_tn(b[:, :V], yc, out=dw, accumulate=c0 > 0)
+    if need:
+      ctx.save_for_backward(dy, dw)
+    return ops.mean(torch.cat(rows))
 
   @staticmethod
   def backward(ctx, g):
-    y, dbuf = ctx.saved_tensors
     lin = ctx.lin
     alpha = g.to(torch.float32).contiguous()
+    sink, p = lin.sink, lin.weight
+    to_sink = sink is not None and sink.active_for(p)
+    if ctx.chunked:
+      dy_un, dw_un = ctx.saved_tensors
+      dy = ops.scale_bf16_(dy_un, alpha) if ctx.needs_input_grad[0] else None  # the saved buffer is ours: scaled in place
+      dw = None
+      if ctx.needs_input_grad[1]:
+        if to_sink:
+          ops.axpy_f32_(p.main_grad, dw_un, alpha, accumulate=not sink.first_write(p))
+          sink.ready(p)
+        else:
+          dw = ops.axpy_f32_(torch.empty_like(dw_un), dw_un, alpha, accumulate=False)
+      return dy, dw, None, None, None
+    y, dbuf = ctx.saved_tensors
     _, wbt = lin.shadow()
     dlogits = dbuf[:, :lin.out_features]
     dy = ops.gemm_nt(dbuf, wbt, alpha=alpha) if ctx.needs_input_grad[0] else None  # K = out_pad, pads are zero on both sides
     dw = None
     if ctx.needs_input_grad[1]:
-      sink, p = lin.sink, lin.weight
-      if sink is not None and sink.active_for(p):
+      if to_sink:
         ops.gemm_tn(dlogits, y, out=p.main_grad, accumulate=not sink.first_write(p), alpha=alpha)
         sink.ready(p)
       else:
         dw = ops.gemm_tn(dlogits, y, alpha=alpha)
-    return dy, dw, None, None
+    return dy, dw, None, None, None

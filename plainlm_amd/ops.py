@@ -366,6 +366,26 @@ def mean(x):
   return out
 
 
+def scale_bf16_(x, alpha):
+  """x <- bf16(x * alpha) in place; alpha is a 0-d fp32 device tensor."""
+  _need(x, BF16, 'scale_bf16.x')
+  _need(alpha, F32, 'scale_bf16.alpha')
+  _lib.check(_lib.load().plm_scale_bf16(_p(x), x.numel(), _p(alpha), _stream()), 'plm_scale_bf16')
+  return x
+
+
+def axpy_f32_(out, x, alpha=None, accumulate=True):
+  """out <- (accumulate ? out : 0) + alpha * x; alpha a 0-d fp32 device tensor (None = 1)."""
+  _need(out, F32, 'axpy.out')
+  _need(x, F32, 'axpy.x')
+  if out.numel() != x.numel():
+    raise ValueError('axpy_f32_: sizes differ')
+  if alpha is not None:
+    _need(alpha, F32, 'axpy.alpha')
+  _lib.check(_lib.load().plm_axpy_f32(_p(out), _p(x), x.numel(), _p(alpha), int(bool(accumulate)), _stream()), 'plm_axpy_f32')
+  return out
+
+
 # ---- optimizer tail ---------------------------------------------------------------------
 def sumsq(x, scratch=None):
   _need(x, F32, 'sumsq.x')

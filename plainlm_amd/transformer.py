@@ -12,6 +12,7 @@ avoids materialising the O(T^2) boolean mask of engine/engine.py:21-23.
 """
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -193,6 +194,8 @@ class Transformer(nn.Module):
 
     self.sink = Fn.GradSink()
     self._flat_grad = None
+    # loss(): token rows per lm_head + cross-entropy chunk (0 = one [M, V] logits buffer)
+    self.head_chunk_rows = int(os.environ.get('PLM_HEAD_CHUNK', '0'))
     self.apply(self._init_weights)
     self._scale_residual_branches()
     if cfg.tie_embeddings:
@@ -298,4 +301,4 @@ class Transformer(nn.Module):
     """Mean token cross-entropy (fp32 scalar) with lm_head + CE fused (never keeps fp32 logits)."""
     y, B, T = self._trunk(x, attn_mask)
     tg = targets.reshape(-1).contiguous()
-    return Fn.HeadLossFn.apply(y, self.lm_head.weight, self.lm_head, tg)
+    return Fn.HeadLossFn.apply(y, self.lm_head.weight, self.lm_head, tg, self.head_chunk_rows)

@@ -509,6 +509,22 @@ def test_cross_entropy_golden(ops, golden_dir):
   assert abs(ref.item() - float(z['ce_loss'])) < 2e-2  # bf16 rounding of the logits only
 
 
+def test_scale_bf16_and_axpy_f32(ops):
+  """The two device-scalar passes of the chunked lm_head + cross-entropy backward."""
+  g = torch.Generator().manual_seed(11)
+  for n in (8, 4099, 1 << 20):
+    x = torch.randn(n, generator=g).to(torch.bfloat16).cuda()
+    alpha = torch.tensor(0.3125, device='cuda')
+    want = (x.float() * 0.3125).to(torch.bfloat16)
+    assert torch.equal(ops.scale_bf16_(x.clone(), alpha), want), n
+    a, b = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    want = torch.addcmul(a.double(), b.double(), torch.tensor(0.3125, dtype=torch.float64, device='cuda')).float()
+    got = ops.axpy_f32_(a.clone(), b, alpha, accumulate=True)
+    assert (got - want).abs().max().item() <= 1e-6, n
+    assert torch.equal(ops.axpy_f32_(torch.full_like(a, float('nan')), b, alpha, accumulate=False), b * 0.3125), n
+    assert torch.equal(ops.axpy_f32_(a.clone(), b, None, accumulate=True), a + b), n
+
+
 # --------------------------------------------------------------------------------------
 # optimizer tail
 # --------------------------------------------------------------------------------------

@@ -106,6 +106,35 @@ def test_reference_style_loss_path(P, mdl):
     assert relmax(p.grad, mdl['g:' + n]) < 4e-2, n
 
 
+@pytest.mark.parametrize('chunk', [32, 48])
+def test_chunked_head_loss_matches_whole_logits_path(P, mdl, chunk):
+  """loss() with the lm_head + cross-entropy walked in row chunks (the [M, V] logits never exist)
+  against the whole-buffer path and the reference's gradients; covers a ragged last chunk, an upstream gradient
+  != 1 (engine.py:118 `loss / accum`), accumulation windows, the autograd-owned .grad path and evaluation."""
+  tok = mdl['tokens']
+  ids, tgt = tok[:, :64].cuda(), tok[:, 1:65].cuda()
+  whole, chunked = _small(P, mdl, main_grad=True), _small(P, mdl, main_grad=True)
+  chunked.head_chunk_rows = chunk  # M = 128: 4 chunks, or 2 + a ragged third
+  for m in (whole, chunked):
+    m.sink.begin_window()
+    (m.loss(ids, tgt) / 4).backward()
+    (m.loss(ids, tgt) / 4).backward()
+  lw, lc = whole.loss(ids, tgt), chunked.loss(ids, tgt)
+  assert torch.equal(lw, lc)  # same per-row kernel, same reduction order
+  ref = mdl['loss'].item()
+  assert abs(lc.item() - ref) <= LOSS_RTOL * abs(ref)
+  assert relmax(chunked._flat_grad, whole._flat_grad) < 2e-3  # bf16 dX rounded before / after the 1/4
+  for n, p in chunked.named_parameters():
+    assert relmax(p.main_grad, 0.5 * mdl['g:' + n]) < 4e-2, n
+  plain = _small(P, mdl)
+  plain.head_chunk_rows = chunk
+  plain.loss(ids, tgt).backward()
+  for n, p in plain.named_parameters():
+    assert relmax(p.grad, mdl['g:' + n]) < 4e-2, n
+  with torch.no_grad():
+    assert torch.equal(plain.loss(ids, tgt), lw)
+
+
 def test_grad_accumulation_and_tied_embeddings(P, mdl):
   m = _small(P, mdl, main_grad=True)
   tok = mdl['tokens']
