@@ -108,26 +108,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
                                                              RopeArgs rope, HybridArgs hyb) {
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
-  static_assert(WM * WN == 8 && TN == 64 && (TM == 128 || TM == 64), "unsupported geometry");
+  static_assert(WM * WN == 8 && (TN == 64 || TN == 96) && (TM == 128 || TM == 64), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
   constexpr int AF = AH / 32;                       // 32-row MFMA fragments per A half
-  constexpr int A_ROWS = BM / 2, B_ROWS = BN / 2;   // rows per half-tile
-  constexpr int A_HT = A_ROWS * 128, B_HT = B_ROWS * 128;
-  constexpr int STAGE = 2 * A_HT + 2 * B_HT;
-  constexpr int A_DMA = A_ROWS / 64, B_DMA = B_ROWS / 64;  // LDS-DMA instructions per thread per half-tile
-  constexpr int OFF_A0 = 0, OFF_B0 = A_HT, OFF_B1 = A_HT + B_HT, OFF_A1 = A_HT + 2 * B_HT;
-  constexpr int W_P4 = A_DMA + B_DMA;  // end of phase 4: B1', A1' may stay in flight
-  constexpr int W_P1 = 2 * A_DMA;      // end of phase 1: A1', A0'' may stay in flight
-  constexpr int W_P2 = A_DMA + B_DMA;  // end of phase 2: A0'', B0'' may stay in flight
+  // A wave's B columns split into "half" 0 = its first BF0 32-column fragments and half 1 = its last fragment
+  // (TN = 64: 1 + 1; TN = 96: 2 + 1 - the 256x192 tile, whose phases 1 and 4 carry twice the MFMAs of 2 and 3).
+  constexpr int BF0 = TN / 32 - 1, NBF = BF0 + 1;
+  constexpr int A_ROWS = BM / 2, B0_ROWS = WN * 32 * BF0, B1_ROWS = WN * 32;  // rows per half-tile
+  constexpr int A_HT = A_ROWS * 128, B0_HT = B0_ROWS * 128, B1_HT = B1_ROWS * 128;
+  constexpr int STAGE = 2 * A_HT + B0_HT + B1_HT;
+  constexpr int A_DMA = A_ROWS / 64, B0_DMA = B0_ROWS / 64, B1_DMA = B1_ROWS / 64;  // LDS-DMA instructions per thread per half-tile
+  static_assert(B0_DMA >= B1_DMA && B1_DMA >= 1, "half-tiles are whole DMA rounds of the workgroup");
+  constexpr int OFF_A0 = 0, OFF_B0 = A_HT, OFF_B1 = A_HT + B0_HT, OFF_A1 = A_HT + B0_HT + B1_HT;
+  constexpr int W_P4 = A_DMA + B1_DMA;  // end of phase 4: B1', A1' may stay in flight
+  constexpr int W_P1 = 2 * A_DMA;       // end of phase 1: A1', A0'' may stay in flight
+  constexpr int W_P2 = A_DMA + B0_DMA;  // end of phase 2: A0'', B0'' may stay in flight
   static_assert(!DEEP || (!STAG && !ONEBAR), "DEEP is a variant of the plain 4-phase schedule");
   // DEEP: groups younger than the one a wait retires (see the schedule above)
-  constexpr int D_P4 = 2 * A_DMA + 3 * B_DMA;  // end of phase 4 -> A0, B0 of kt+1: B1', A1', A0'', B0'', B1'' in flight
-  constexpr int D_P1 = 3 * A_DMA + 2 * B_DMA;  // end of phase 1 -> B1 of kt: A1, A0', B0', B1', A1' in flight
-  constexpr int D_P2 = 3 * A_DMA + 2 * B_DMA;  // end of phase 2 -> A1 of kt: A0', B0', B1', A1', A0'' in flight
+  constexpr int D_P4 = 2 * A_DMA + B0_DMA + 2 * B1_DMA;  // end of phase 4 -> A0, B0 of kt+1: B1', A1', A0'', B0'', B1'' in flight
+  constexpr int D_P1 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 1 -> B1 of kt: A1, A0', B0', B1', A1' in flight
+  constexpr int D_P2 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 2 -> A1 of kt: A0', B0', B1', A1', A0'' in flight
   // DEEP: the C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
-  constexpr int NS = 2 * AF * 4;
+  constexpr int NS = 2 * AF * 2 * NBF;
   static_assert(!DEEP || D_P1 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // instruction: 3-5 % faster (run 27).  The 4-phase kernels keep per-lane 64-bit pointers and the builtin (the asm form
   // measured 1 % slower there: two instructions per phase leave hipcc nothing to schedule around).
   constexpr bool SADDR = ONEBAR;
-  unsigned oa[2][A_DMA], ob[2][B_DMA];
+  unsigned oa[2][A_DMA], ob[2][B0_DMA];
   const uint16_t* s_ab = A;
   const uint16_t* s_bb = B;
   auto set_ptrs = [&](int m0, int n0) {
@@ -205,10 +209,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         oa[h][i] = (unsigned)(((int64_t)m * lda + chunk * 8) * 2);
       }
 #pragma unroll
-      for (int i = 0; i < B_DMA; ++i) {
+      for (int i = 0; i < (h ? B1_DMA : B0_DMA); ++i) {
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int n = min((r / 32) * TN + h * 32 + (r % 32), N - 1 - n0);
+        const int rw = h ? 32 : 32 * BF0;  // rows of one wave inside this half-tile
+        const int n = min((r / rw) * TN + h * 32 * BF0 + (r % rw), N - 1 - n0);
         ob[h][i] = (unsigned)(((int64_t)n * ldb + chunk * 8) * 2);
       }
     }
@@ -224,7 +229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   auto issue_b = [&](int h, char* stage, int k0) {
     char* dst = stage + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
-    for (int i = 0; i < B_DMA; ++i) {
+    for (int i = 0; i < B0_DMA; ++i) {
+      if (i >= (h ? B1_DMA : B0_DMA)) continue;
       if (SADDR) dma16_saddr_asm(s_bb + k0, ob[h][i], dst + (i * 8 + wave) * 1024);
       else big_dma16(reinterpret_cast<const char*>(s_bb + k0) + ob[h][i], dst + (i * 8 + wave) * 1024);
     }
@@ -294,11 +300,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     int m0 = 0, n0 = 0, kbeg = 0, kend = K, split = -1;
     if (HYB) take(cc, m0, n0, kbeg, kend, split);
     const int nk = HYB ? (kend - kbeg) / 64 : nkt;
-    f32x16_t acc[2 * AF][2];
+    f32x16_t acc[2 * AF][NBF];
 #pragma unroll
     for (int i = 0; i < 2 * AF; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NBF; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       bool more = s_item < ntiles;  // workgroup-uniform: the staging cursor still points at a K-tile
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
-      bf16x8_t a[AF][4], b0[4], b1[4];
+      bf16x8_t a[AF][4], b0[BF0][4], b1[4];
 
       // end of a phase's READ section / MFMA section
       auto end_read = [&](auto wtag) {
@@ -348,7 +354,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        b0[ks] = frag(cur + OFF_B0, wn * 32 + l31, ks);
+#pragma unroll
+        for (int j = 0; j < BF0; ++j) b0[j][ks] = frag(cur + OFF_B0, (wn * BF0 + j) * 32 + l31, ks);
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
       }
@@ -359,7 +366,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(b0[ks], a[f][ks], acc[f][0]);
+        for (int f = 0; f < AF; ++f)
+#pragma unroll
+          for (int j = 0; j < BF0; ++j) acc[f][j] = mfma32(b0[j][ks], a[f][ks], acc[f][j]);
       if (STAG) end_mfma(); else end_read(integral_constant<int, DEEP ? D_P1 : W_P1>{});
 
       // ---- phase 2: quadrant (A0, B1); stage B0 (DEEP: A0 two K-tiles ahead, into the slot phase 1 just read)
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(b1[ks], a[f][ks], acc[f][1]);
+        for (int f = 0; f < AF; ++f) acc[f][BF0] = mfma32(b1[ks], a[f][ks], acc[f][BF0]);
       if (STAG) end_mfma(); else end_read(integral_constant<int, DEEP ? D_P2 : W_P2>{});
 
       // ---- phase 3: quadrant (A1, B1); stage B1 (DEEP: B0).  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(b1[ks], a[f][ks], acc[AF + f][1]);
+        for (int f = 0; f < AF; ++f) acc[AF + f][BF0] = mfma32(b1[ks], a[f][ks], acc[AF + f][BF0]);
       if (STAG) end_mfma();
 
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1 (DEEP: B1)
@@ -414,7 +423,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(b0[ks], a[f][ks], acc[AF + f][0]);
+        for (int f = 0; f < AF; ++f)
+#pragma unroll
+          for (int j = 0; j < BF0; ++j) acc[AF + f][j] = mfma32(b0[j][ks], a[f][ks], acc[AF + f][j]);
       if (STAG) {
         end_mfma();
       } else if (ONEBAR) {
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         const int gm = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32 + l31;
         if (gm >= M) continue;
 #pragma unroll
-        for (int bh = 0; bh < 2; ++bh) {
+        for (int bh = 0; bh < NBF; ++bh) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int gn = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;
@@ -456,46 +467,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
       const int tpos = ROPE ? (mrow0 + l31) % rope.T : 0;  // token position of this lane's row
+      // the wave's TN columns leave in passes of up to 64 (TN = 96: 64 + 32)
 #pragma unroll
-      for (int bh = 0; bh < 2; ++bh) {
+      for (int p0 = 0; p0 < NBF; p0 += 2) {
+        const int nb = NBF - p0 < 2 ? NBF - p0 : 2;  // 32-column blocks of this pass
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4_t o;
-          if (ROPE) {
-            const int ncol = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns
-            float v0 = acc[mf][bh][4 * g + 0] * alpha, v1 = acc[mf][bh][4 * g + 1] * alpha;
-            float v2 = acc[mf][bh][4 * g + 2] * alpha, v3 = acc[mf][bh][4 * g + 3] * alpha;
-            if (ncol < rope.cols) {
-              const int pi = tpos * 32 + (ncol & 63) / 2;  // even: the two pairs' table entries are one aligned 8-byte load each
-              typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-              const f32x2_t cc = *reinterpret_cast<const f32x2_t*>(rope.cos_t + pi);
-              const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(rope.sin_t + pi);
-              const float c0 = cc[0], c1 = cc[1], s0 = ss[0], s1 = ss[1];
-              const float a0 = v0, b0 = v1, a1 = v2, b1 = v3;
-              v0 = a0 * c0 - b0 * s0;
-              v1 = b0 * c0 + a0 * s0;
-              v2 = a1 * c1 - b1 * s1;
-              v3 = b1 * c1 + a1 * s1;
+        for (int bq = 0; bq < 2; ++bq) {
+          if (bq >= nb) continue;
+          const int bh = p0 + bq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4_t o;
+            if (ROPE) {
+              const int ncol = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns
+              float v0 = acc[mf][bh][4 * g + 0] * alpha, v1 = acc[mf][bh][4 * g + 1] * alpha;
+              float v2 = acc[mf][bh][4 * g + 2] * alpha, v3 = acc[mf][bh][4 * g + 3] * alpha;
+              if (ncol < rope.cols) {
+                const int pi = tpos * 32 + (ncol & 63) / 2;  // even: the two pairs' table entries are one aligned 8-byte load each
+                typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                const f32x2_t cc = *reinterpret_cast<const f32x2_t*>(rope.cos_t + pi);
+                const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(rope.sin_t + pi);
+                const float c0 = cc[0], c1 = cc[1], s0 = ss[0], s1 = ss[1];
+                const float a0 = v0, b0 = v1, a1 = v2, b1 = v3;
+                v0 = a0 * c0 - b0 * s0;
+                v1 = b0 * c0 + a0 * s0;
+                v2 = a1 * c1 - b1 * s1;
+                v3 = b1 * c1 + a1 * s1;
+              }
+              o[0] = f2bf(v0); o[1] = f2bf(v1); o[2] = f2bf(v2); o[3] = f2bf(v3);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
             }
-            o[0] = f2bf(v0); o[1] = f2bf(v1); o[2] = f2bf(v2); o[3] = f2bf(v3);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
+            const int c = bq * 4 + g;  // 16-byte chunk of the pass's row; this lane fills half `hi` of it
+            *reinterpret_cast<bf16x4_t*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4) + hi * 8) = o;
           }
-          const int c = bh * 4 + g;  // 16-byte chunk of the 64-column row; this lane fills half `hi` of it
-          *reinterpret_cast<bf16x4_t*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4) + hi * 8) = o;
         }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c >> 3, ch = c & 7;
-        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
-        const int gm = mrow0 + row, gn = n0 + wn * TN + ch * 8;
-        if (gm < M && gn < N) st_bf16x8(C + (int64_t)gm * ldc + gn, v);
+        for (int it = 0; it < 4; ++it) {
+          if (it >= 2 * nb) continue;
+          const int c = it * 64 + lane;
+          const int row = nb == 2 ? c >> 3 : c >> 2, ch = nb == 2 ? c & 7 : c & 3;
+          const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
+          const int gm = mrow0 + row, gn = n0 + wn * TN + p0 * 32 + ch * 8;
+          if (gm < M && gn < N) st_bf16x8(C + (int64_t)gm * ldc + gn, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     credit = DEEP && m0 + BM <= M && n0 + BN <= N;  // interior tile: every wave issued exactly NS stores
   }
@@ -1097,10 +1116,14 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int tm = (int)plm_cdiv(M, 256);
-  const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128);
+  const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
   const int slots = persistent_slots();
   const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
   const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * (getenv("PLM_E128") ? atof(getenv("PLM_E128")) : 0.88);  // lower intensity (measured: 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape)
+  // 256x192 (wave tile 64x96): 22 % fewer LDS-DMA bytes and 17 % fewer LDS reads per MFMA than 256x128; N = 768 is 4 tile
+  // columns = exactly two rounds of 256 CUs at M = 32768
+  static const double f192 = getenv("PLM_E192") ? atof(getenv("PLM_E192")) : 0.94;
+  const double e192 = round_efficiency((int64_t)tm * tn192, slots) * ((double)N / (tn192 * 192.0)) * f192;
   // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
   // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
   const dim3 block(512);
@@ -1147,6 +1170,13 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
     else
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
                          (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    return true;
+  }
+  if (variant == 12 || (variant == 0 && !rope_cos && e192 > e256 && e192 > e128 && M >= 512 && getenv("PLM_NO_192") == nullptr)) {
+    const int nt_ = tm * tn192;
+    const dim3 g(nt_ < slots ? nt_ : slots);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                       (int)N, (int)K, alpha_dev, tm, tn192, RopeArgs{nullptr, nullptr, 0, 0}, hyb);
     return true;
   }
   if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip); whole tiles only, other shapes run as variant 3

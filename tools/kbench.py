@@ -70,7 +70,7 @@ def main():
         rec(name + ' [no hybrid]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
         del os.environ['PLM_NT_NO_HYBRID']
       if k % 64 == 0 and a.variants:
-        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (10, 'deep256x256'), (11, 'deep256x128'), (5, 'stag256x256'), (6, 'stag256x128')):
+        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (10, 'deep256x256'), (11, 'deep256x128'), (12, 'deep256x192'), (5, 'stag256x256'), (6, 'stag256x128')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
         rec(f'{name} [auto again]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
       del A, Bm, out
