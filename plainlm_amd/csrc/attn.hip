@@ -139,6 +139,20 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv
 // =============================================================================================
 // forward (q, k already rotated)
 // =============================================================================================
+// Block -> (128-row tile, head, batch).  A causal tile's work grows linearly with its index (2 .. 2*T/128 key tiles), and the
+// hardware hands blocks out in blockIdx order, so the order is tile-major: ALL blocks of the heaviest tile index first,
+// the lightest last (longest-processing-time-first; with the (tile, h, b) 3-D grid every (h, b) group ended on its own
+// light tiles but the last groups' heavy blocks ran on into a ~40 % tail at falling occupancy - 2.1 of 5 possible waves
+// per SIMD on average, run 30 counters).
+__device__ __forceinline__ void attn_block(int T, int nh, int& tile, int& h, int& b) {
+  const int ntile = (T + 127) / 128;
+  const int nbh = gridDim.x / ntile;
+  const int bh = blockIdx.x % nbh;
+  tile = blockIdx.x / nbh;
+  h = bh % nh;
+  b = bh / nh;
+}
+
 template <bool HAS_DOC>
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
@@ -146,9 +160,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
   constexpr int TILE = KT * 128;    // 8 KiB
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE];  // [stage][K|V]
 
-  const int nqt = gridDim.x;
-  const int qt = nqt - 1 - blockIdx.x;  // heaviest (latest) query tiles first
-  const int h = blockIdx.y, b = blockIdx.z;
+  int tile_, h, b;
+  attn_block(T, nh, tile_, h, b);
+  const int qt = (T + 127) / 128 - 1 - tile_;  // heaviest (latest) query tiles first
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -307,7 +321,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   constexpr int STAGE = 2 * TILE + 1024;   // Q | dO | statistics (lse[64], delta[64], doc_start[64])
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
-  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  int kt, h, b;  // key tile 0 meets every query tile: heaviest first
+  attn_block(T, nh, kt, h, b);
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -481,9 +496,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   constexpr int TILE = KT * 128;
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE];  // [stage][K|V]
 
-  const int nqt = gridDim.x;
-  const int qt = nqt - 1 - blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int tile_, h, b;
+  attn_block(T, nh, tile_, h, b);
+  const int qt = (T + 127) / 128 - 1 - tile_;
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -645,7 +660,7 @@ extern "C" int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint1
                             int64_t hd, void* stream) {
   PLM_REQUIRE(qkv && out && lse, "plm_attn_fwd: null pointer");
   if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
-  const dim3 grid((unsigned)plm_cdiv(T, 128), (unsigned)nh, (unsigned)B), block(256);
+  const dim3 grid((unsigned)(plm_cdiv(T, 128) * nh * B)), block(256);  // see attn_block
   hipStream_t s = (hipStream_t)stream;
   if (doc_start)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
@@ -663,7 +678,7 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(256);
   // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
-  const dim3 gkv((unsigned)plm_cdiv(T, 128), (unsigned)nh, (unsigned)B);
+  const dim3 gkv((unsigned)(plm_cdiv(T, 128) * nh * B));
   if (doc_start) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
