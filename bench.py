@@ -160,9 +160,11 @@ def main():
   params = list(model.parameters())
 
   reducer = None
-  if world > 1:
+  force_reducer = world == 1 and os.environ.get('PLM_FORCE_REDUCER')  # one-GPU what-if: the whole DDP data plane with a 1-rank communicator
+  if world > 1 or force_reducer:
     comm = ddp.make_comm(device, a.comm)
-    reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb)
+    reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
+                              reserve_cus=ddp.COMM_CUS if force_reducer else None)
     reducer.broadcast_params([p.data for p in params])
     model.sink.on_ready = reducer.param_ready
 
@@ -267,7 +269,8 @@ def main():
       from plainlm_amd.optim import FlatAdamW
       opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
       if reducer is not None:
-        reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb)
+        reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
+                                  reserve_cus=reducer.reserve_cus)
         model.sink.on_ready = reducer.param_ready
 
       def full(i):

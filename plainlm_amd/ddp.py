@@ -20,9 +20,12 @@ import torch.distributed as dist
 from . import _lib
 
 
-# CUs kept free for RCCL's kernels while gradients are exchanged during backward, and the matching cap on RCCL
-# channels (one workgroup each).  160M fp32 gradients are 650 MB per step: even 8 channels move that well inside a
-# ~25 ms backward over xGMI, and the persistent GEMMs keep a whole number of rounds on the remaining CUs.
+# CUs kept free for RCCL's kernels while gradient buckets are in flight, and the matching cap on RCCL channels (one
+# workgroup each).  The persistent GEMMs launch one workgroup per CU; a workgroup that finds its CU taken by a collective
+# would run after the others (a second round), so the GEMM grids shrink by this many while - and only while - an
+# all-reduce may be running: GradReducer sets the reserve when the first bucket of a step is launched and clears it in
+# finish(), so the forward pass and the lm_head backward (no collective in flight) keep all 256 CUs (the reserve costs
+# 5.5 % on the GEMMs it applies to, run 30).
 COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
 
 
@@ -45,9 +48,6 @@ class RcclComm:
     _lib.check(lib.plm_comm_init(C.byref(handle), C.cast(uid, C.c_void_p), rank, world_size, device_index), 'plm_comm_init')
     self.handle, self.lib = handle, lib
     self.rank, self.world_size = rank, world_size
-    if world_size > 1:
-      from . import ops
-      ops.set_cu_reserve(COMM_CUS)
 
   def allreduce_avg_(self, span, stream):
     _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),
@@ -118,7 +118,7 @@ class GradReducer:
       reducer.finish()                           # after backward, before clip/optimizer
   """
 
-  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False):
+  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False, reserve_cus=None):
     self.flat = flat_grad
     self.comm = comm
     self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)))
@@ -134,6 +134,11 @@ class GradReducer:
     self.sync = False
     self.pending = None
     self.launched = []
+    # CUs left to the collectives between the first bucket launch of a step and finish() (see COMM_CUS)
+    if reserve_cus is None:
+      reserve_cus = COMM_CUS if (self.on_gpu and comm.world_size > 1) else 0
+    self.reserve_cus = int(reserve_cus) if self.on_gpu else 0
+    self._reserved = False
 
   def begin(self, sync):
     self.sync = bool(sync) and (self.comm.world_size > 1 or self.force)
@@ -149,6 +154,10 @@ class GradReducer:
       self.stream.wait_event(ev)
       with torch.cuda.stream(self.stream):
         self.comm.allreduce_avg_(span, self.stream)
+      if self.reserve_cus and not self._reserved:  # GEMMs enqueued from here on may run beside a collective
+        from . import ops
+        ops.set_cu_reserve(self.reserve_cus)
+        self._reserved = True
     else:
       self.comm.allreduce_avg_(span, None)
     self.launched.append(b)
@@ -173,6 +182,10 @@ class GradReducer:
         self._launch(b)
     if self.on_gpu:
       torch.cuda.current_stream().wait_stream(self.stream)
+    if self._reserved:  # everything enqueued after the join runs with no collective in flight
+      from . import ops
+      ops.set_cu_reserve(0)
+      self._reserved = False
     self.sync = False
 
   def broadcast_params(self, flat_params_or_list):
@@ -213,8 +226,6 @@ def make_comm(device, backend=None, group=None):
       comm.close()
     print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl', flush=True)
     os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
-    from . import ops
-    ops.set_cu_reserve(COMM_CUS)
     return TorchDistComm(dist.new_group(backend='nccl'))
   if not dist.is_initialized():
     raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")

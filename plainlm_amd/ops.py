@@ -184,16 +184,25 @@ _tn_ws = {}
 _nt_ws_cache = {}
 
 
+_cu_reserve = 0
+
+
 def set_cu_reserve(n):
-  """Leave n CUs out of the persistent GEMM grids (RCCL runs there during backward); plans change, so drop the cache."""
+  """Leave n CUs out of the persistent GEMM grids (RCCL's kernels run there while gradient buckets are in flight); every
+  plan (tile shape, hybrid stream-K, split-K) is recomputed per launch from the current value."""
+  global _cu_reserve
   _lib.check(_lib.load().plm_set_cu_reserve(int(n)), 'plm_set_cu_reserve')
-  _nt_ws_cache.clear()
+  _cu_reserve = int(n)
+
+
+def cu_reserve():
+  return _cu_reserve
 
 
 def _nt_ws_bytes(lib, M, N, K):
-  """Workspace query of the hybrid NT schedule, cached per shape (the plan depends on the shape, the PLM_NT_* environment knobs -
-  part of the key - and the CU reserve, whose setter clears the cache)."""
-  key = (M, N, K, os.environ.get('PLM_NT_NO_HYBRID'), os.environ.get('PLM_NT_HYBRID_MIN_K'))
+  """Workspace query of the hybrid NT schedule, cached per shape (the plan depends on the shape, the PLM_NT_* environment knobs
+  and the CU reserve - all part of the key)."""
+  key = (M, N, K, _cu_reserve, os.environ.get('PLM_NT_NO_HYBRID'), os.environ.get('PLM_NT_HYBRID_MIN_K'))
   v = _nt_ws_cache.get(key)
   if v is None:
     v = _nt_ws_cache[key] = int(lib.plm_gemm_nt_workspace_bytes(M, N, K))

@@ -254,7 +254,7 @@ def test_gemm_nt_hybrid(ops, M, N, K, monkeypatch):
 
 
 def test_gemms_with_cu_reserve(ops, monkeypatch):
-  """Multi-GPU runs reserve 16 CUs for RCCL (ddp.RcclComm -> ops.set_cu_reserve): the persistent grids shrink to 240
+  """Multi-GPU runs reserve 16 CUs for RCCL while gradient buckets are in flight (ddp.GradReducer -> ops.set_cu_reserve): the persistent grids shrink to 240
   workgroups and every plan (tile choice, hybrid stream-K, TN split) is recomputed for that count.  Same answers required."""
   monkeypatch.setenv('PLM_NT_HYBRID_MIN_K', '64')
   g = torch.Generator(device='cuda').manual_seed(11)

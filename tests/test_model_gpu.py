@@ -334,8 +334,9 @@ def test_rccl_reducer_single_rank(P, mdl):
   torch.cuda.synchronize()
   want = m._flat_grad.clone()
   comm = ddp.RcclComm(0, 1, torch.cuda.current_device())
-  red = ddp.GradReducer(m._flat_grad, list(m.parameters()), m._grad_spans, comm, bucket_cap_mb=0.25, force=True)
-  assert len(red.buckets) >= 4
+  from plainlm_amd import ops
+  red = ddp.GradReducer(m._flat_grad, list(m.parameters()), m._grad_spans, comm, bucket_cap_mb=0.25, force=True, reserve_cus=16)
+  assert len(red.buckets) >= 4 and ops.cu_reserve() == 0
   red.broadcast_params([p.data for p in m.parameters()])
   m.sink.on_ready = red.param_ready
   fired = []
@@ -345,7 +346,9 @@ def test_rccl_reducer_single_rank(P, mdl):
   red.begin(sync=True)
   m.loss(ids, tgt).backward()
   n_during_backward = len(fired)
+  assert ops.cu_reserve() == 16  # CUs are set aside from the first bucket launch ...
   red.finish()
+  assert ops.cu_reserve() == 0   # ... until the streams are joined
   torch.cuda.synchronize()
   assert n_during_backward == len(red.buckets) == len(fired)  # every bucket launched from inside backward
   assert sum(fired) == m._flat_grad.numel()
