@@ -101,7 +101,7 @@ struct HybridArgs {
 // half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups
 // (80 KiB for 256x256) are in flight behind every counted wait instead of two.  Measured (profiles/r01_kbench_run19*):
 // global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deeper queue lets them overlap.
-template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false, bool DEEP = false>
+template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false, bool DEEP = false, bool P2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -128,11 +128,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   constexpr int D_P4 = 2 * A_DMA + B0_DMA + 2 * B1_DMA;  // end of phase 4 -> A0, B0 of kt+1: B1', A1', A0'', B0'', B1'' in flight
   constexpr int D_P1 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 1 -> B1 of kt: A1, A0', B0', B1', A1' in flight
   constexpr int D_P2 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 2 -> A1 of kt: A0', B0', B1', A1', A0'' in flight
+  // P2 (two-phase form of DEEP): phase A = quadrants (A0,B0),(A0,B1), phase B = (A1,B1),(A1,B0); two barriers per K-tile, each
+  // merged with a counted wait.  Barrier A (all reads of A0/B0/B1 done, A1 of this K-tile landed) is followed by ALL the DMA
+  // issue of the K-tile: A1 of kt+1, then A0, B0, B1 of kt+2 into the slots just released; barrier B waits for A0, B0, B1 of kt+1.
+  static_assert(!P2 || DEEP, "P2 is a variant of the deep-prefetch ring");
+  constexpr int P_WA = A_DMA + B0_DMA + B1_DMA;      // A0', B0', B1' may stay in flight
+  constexpr int P_WB = 2 * A_DMA + B0_DMA + B1_DMA;  // A1', A0'', B0'', B1'' may stay in flight
   // DEEP: the C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
   constexpr int NS = 2 * AF * 2 * NBF;
   static_assert(!DEEP || D_P1 + NS < 64, "vmcnt is a 6-bit counter");
+  static_assert(!P2 || P_WB + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       issue_a(0, smem + STAGE, s_k);
       issue_b(0, smem + STAGE, s_k);
       issue_b(1, smem + STAGE, s_k);
-      wait_vm<D_P4>();
+      wait_vm<P2 ? A_DMA + P_WA : D_P4>();  // P2: phase A reads B1 as well - only A1 and the second K-tile's pieces stay in flight
     } else {
       wait_vm<0>();
     }
@@ -313,6 +320,59 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[BF0][4], b1[4];
+      if (P2) {
+        // ---- phase A: reads A0, B0, B1
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int j = 0; j < BF0; ++j) b0[j][ks] = frag(cur + OFF_B0, (wn * BF0 + j) * 32 + l31, ks);
+#pragma unroll
+          for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
+          b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
+        }
+        if (!more) wait_vm<0>();
+        else if (credit) wait_vm<P2 ? P_WA + NS : 0>();
+        else wait_vm<P_WA>();
+        phase_barrier();
+        if (more) {
+          issue_a(1, smem + s_st * STAGE, s_k);
+          advance_staged();
+          more = s_item < ntiles;
+        }
+        if (more) {
+          issue_a(0, smem + s_st * STAGE, s_k);
+          issue_b(0, smem + s_st * STAGE, s_k);
+          issue_b(1, smem + s_st * STAGE, s_k);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int f = 0; f < AF; ++f) {
+#pragma unroll
+            for (int j = 0; j < BF0; ++j) acc[f][j] = mfma32(b0[j][ks], a[f][ks], acc[f][j]);
+            acc[f][BF0] = mfma32(b1[ks], a[f][ks], acc[f][BF0]);
+          }
+        // ---- phase B: reads A1
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A1, wm * AH + f * 32 + l31, ks);
+        if (!more) wait_vm<0>();
+        else if (credit) wait_vm<P2 ? P_WB + NS : 0>();
+        else wait_vm<P_WB>();
+        phase_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int f = 0; f < AF; ++f) {
+            acc[AF + f][BF0] = mfma32(b1[ks], a[f][ks], acc[AF + f][BF0]);
+#pragma unroll
+            for (int j = 0; j < BF0; ++j) acc[AF + f][j] = mfma32(b0[j][ks], a[f][ks], acc[AF + f][j]);
+          }
+        credit = false;
+        st ^= 1;
+        continue;
+      }
 
       // end of a phase's READ section / MFMA section
       auto end_read = [&](auto wtag) {
@@ -1172,9 +1232,32 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
                          (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
     return true;
   }
+  static const int p2_max_k = getenv("PLM_GEMM_P2") ? atoi(getenv("PLM_GEMM_P2")) : 0;  // two-phase ring for K <= this (A/B knob)
+  const bool env_p2 = K <= p2_max_k;
+  if (variant >= 13 && variant <= 15) {  // two-phase deep-prefetch ring: 256x256 / 256x192 / 256x128
+    const RopeArgs nr{nullptr, nullptr, 0, 0};
+    const int tn_ = variant == 13 ? tn256 : variant == 14 ? tn192 : tn128;
+    const int nt_ = tm * tn_;
+    const dim3 g(nt_ < slots ? nt_ : slots);
+    if (variant == 13)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    else if (variant == 14)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    else
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    return true;
+  }
   if (variant == 12 || (variant == 0 && !rope_cos && e192 > e256 && e192 > e128 && M >= 512 && getenv("PLM_NO_192") == nullptr)) {
     const int nt_ = tm * tn192;
     const dim3 g(nt_ < slots ? nt_ : slots);
+    if (variant == 0 && env_p2) {
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn192, RopeArgs{nullptr, nullptr, 0, 0}, hyb);
+      return true;
+    }
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
                        (int)N, (int)K, alpha_dev, tm, tn192, RopeArgs{nullptr, nullptr, 0, 0}, hyb);
     return true;
@@ -1222,12 +1305,18 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
                          (int)K, alpha_dev, tm, tn128, rope, hyb);
   } else if (use256) {
     if (stag) PLM_NTB(256, 2, 4, true, false, tn256);
+    else if (variant == 0 && env_p2)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn256, rope, hyb);
     else if (variant == 0)  // automatic long-K choice: the deep-prefetch form of the 4-phase schedule (2-6 % faster, run 19)
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
                          (int)N, (int)K, alpha_dev, tm, tn256, rope, hyb);
     else PLM_NTB(256, 2, 4, false, false, tn256);
   } else {
     if (stag) PLM_NTB(128, 4, 2, true, false, tn128);
+    else if (variant == 0 && env_p2)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                         (int)N, (int)K, alpha_dev, tm, tn128, rope, hyb);
     else if (variant == 0)
       hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
                          (int)N, (int)K, alpha_dev, tm, tn128, rope, hyb);

@@ -29,6 +29,24 @@ def timeit(fn, iters, warmup=12):  # enough launches for clocks / caches to sett
   return s.elapsed_time(e) / iters  # ms
 
 
+def timeit_instep(fns, iters, between, warmup=6):
+  """In-step conditions: rotate over several operand sets (nothing stays cache-resident from the previous launch of the same
+  shape) and run an HBM-bound kernel between GEMM launches (as the norm / activation kernels of the step do); only the GEMM
+  launches are timed, one event pair each."""
+  for i in range(warmup):
+    between()
+    fns[i % len(fns)]()
+  torch.cuda.synchronize()
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+  for i, (s, e) in enumerate(evs):
+    between()
+    s.record()
+    fns[i % len(fns)]()
+    e.record()
+  torch.cuda.synchronize()
+  return sum(s.elapsed_time(e) for s, e in evs) / iters
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--iters', type=int, default=20)
@@ -37,6 +55,7 @@ def main():
   ap.add_argument('--T', type=int, default=1024)
   ap.add_argument('--json', default='')
   ap.add_argument('--variants', action='store_true', help='also time every NT kernel variant per shape')
+  ap.add_argument('--instep', action='store_true', help='NT variants under in-step conditions: rotating operand sets + an HBM-bound kernel between launches')
   a = ap.parse_args()
   only = set(a.only.split(',')) if a.only else None
   B, T, d, nh, h, V = a.B, a.T, 768, 12, 2048, 50280
@@ -70,9 +89,19 @@ def main():
         rec(name + ' [no hybrid]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
         del os.environ['PLM_NT_NO_HYBRID']
       if k % 64 == 0 and a.variants:
-        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (10, 'deep256x256'), (11, 'deep256x128'), (12, 'deep256x192'), (5, 'stag256x256'), (6, 'stag256x128')):
+        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (10, 'deep256x256'), (11, 'deep256x128'), (12, 'deep256x192'), (13, 'p2_256x256'), (14, 'p2_256x192'), (15, 'p2_256x128'), (5, 'stag256x256'), (6, 'stag256x128')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
         rec(f'{name} [auto again]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
+      if k % 64 == 0 and a.instep and n < 10000:
+        sets = [(torch.randn(m, k, device=dev).to(BF), torch.randn(n, k, device=dev).to(BF) * 0.02, torch.empty(m, n, device=dev, dtype=BF))
+                for _ in range(4)]
+        big = torch.randn(M, 4096, device=dev).to(BF)
+        between = lambda: ops.swiglu_fwd(big)  # 268 MB read + 134 MB written: evicts L2 / most of the Infinity Cache
+        for v, vn in ((0, 'auto'), (10, 'deep256x256'), (13, 'p2_256x256'), (7, 'onebar256x256'), (12, 'deep256x192'), (14, 'p2_256x192'),
+                      (11, 'deep256x128'), (15, 'p2_256x128'), (8, 'onebar256x128')):
+          fns = [(lambda X=X, W=W, O=O: ops.gemm_nt(X, W, out=O, variant=v)) for X, W, O in sets]
+          rec(f'{name} [in-step {vn}]', timeit_instep(fns, a.iters, between), flops=2.0 * m * n * k)
+        del sets, big
       del A, Bm, out
     for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
                              'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}.items():
