@@ -650,7 +650,7 @@ extern "C" int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* ro
   if (int rc = check_attn_shape("plm_rope_qk", B, T, nh, hd)) return rc;
   const int64_t items = B * T * (2 * nh * hd / 8);
   int64_t blocks = plm_cdiv(items, 256);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > ((int64_t)1 << 20)) blocks = (int64_t)1 << 20;  // one item per thread in memory order (see elementwise_grid)
   hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, qkv, rope_cos, rope_sin, B * T, (int)T, (int)nh);
   PLM_CHECK_LAUNCH("plm_rope_qk");
   return PLM_OK;

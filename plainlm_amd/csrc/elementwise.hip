@@ -59,7 +59,7 @@ extern "C" int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, voi
   PLM_REQUIRE(src && dst && n >= 0, "plm_cast_f32_bf16: null pointer or negative n");
   if (n == 0) return PLM_OK;
   const int64_t work = plm_cdiv(plm_cdiv(n, 8), 256);
-  const int grid = (int)(work < 4096 ? (work < 1 ? 1 : work) : 4096);
+  const int grid = (int)(work < ((int64_t)1 << 20) ? (work < 1 ? 1 : work) : ((int64_t)1 << 20));
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n);
   PLM_CHECK_LAUNCH("plm_cast_f32_bf16");
   return PLM_OK;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ out, 
 
 static int plm_stream_grid(int64_t nvec) {
   const int64_t work = plm_cdiv(nvec, 256);
-  return (int)(work < 4096 ? (work < 1 ? 1 : work) : 4096);
+  return (int)(work < ((int64_t)1 << 20) ? (work < 1 ? 1 : work) : ((int64_t)1 << 20));
 }
 
 extern "C" int plm_scale_bf16(uint16_t* x, int64_t n, const float* alpha_dev, void* stream) {
@@ -588,9 +588,13 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restr
   }
 }
 
+// One item per thread, blocks in memory order: a grid capped at 8192 blocks with a grid-stride loop (every resident block
+// a stride apart) measured 4-5 % slower on the SwiGLU kernels and 29 % slower on AdamW (0.95 -> 0.74 ms for 162M parameters)
+// than letting the dispatcher walk memory linearly (run 32); the stride loop only remains for > 2^20 blocks.
 static int elementwise_grid(int64_t items) {
+  const int64_t cap = (int64_t)1 << 20;
   const int64_t b = plm_cdiv(items, 256);
-  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 extern "C" int plm_swiglu_fwd(const uint16_t* u, uint16_t* out, int64_t M, int64_t h, void* stream) {
