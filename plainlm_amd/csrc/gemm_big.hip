@@ -101,7 +101,7 @@ struct HybridArgs {
 // half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups
 // (80 KiB for 256x256) are in flight behind every counted wait instead of two.  Measured (profiles/r01_kbench_run19*):
 // global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deeper queue lets them overlap.
-template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false, bool DEEP = false, bool P2 = false>
+template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false, bool DEEP = false, bool P2 = false, bool OFFS = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -132,6 +132,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // merged with a counted wait.  Barrier A (all reads of A0/B0/B1 done, A1 of this K-tile landed) is followed by ALL the DMA
   // issue of the K-tile: A1 of kt+1, then A0, B0, B1 of kt+2 into the slots just released; barrier B waits for A0, B0, B1 of kt+1.
   static_assert(!P2 || DEEP, "P2 is a variant of the deep-prefetch ring");
+  // OFFS (offset wave groups, deep ring only): waves w and w+4 share a SIMD.  With every wave on the same schedule both do their
+  // DMA issue + LDS reads at the same time and then queue for the matrix pipe: a phase costs overhead + 2 x MFMA time.  Here the
+  // second group (waves 4-7) takes each barrier BETWEEN the reads and the MFMAs of a phase instead of behind the MFMAs - same
+  // code, same three barriers per K-tile and wave, same slots and waits - so inside every barrier interval group 0 runs
+  // reads(p), MFMAs(p) while group 1 runs MFMAs(p-1), reads(p): one wave's reads and DMA issue sit under the other's MFMAs.
+  static_assert(!OFFS || (DEEP && !P2), "OFFS is a variant of the 4-phase deep-prefetch ring");
   constexpr int P_WA = A_DMA + B0_DMA + B1_DMA;      // A0', B0', B1' may stay in flight
   constexpr int P_WB = 2 * A_DMA + B0_DMA + B1_DMA;  // A1', A0'', B0'', B1'' may stay in flight
   // DEEP: the C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const bool grp1 = OFFS && (wave >> 2) != 0;  // wave-uniform
   const int l31 = lane & 31, hi = lane >> 5;
   // HYB = false instantiations keep the plain schedule free of the stream-K bookkeeping
   const int rfull = HYB ? hyb.rfull : tiles_m;
@@ -423,13 +430,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         if (more) issue_a(0, nxt, s_k);  // behind the reads: their latency hides the DMA issue
         end_read(integral_constant<int, W_P1>{});
       }
+      if (OFFS && grp1) end_read(integral_constant<int, D_P1>{});
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f)
 #pragma unroll
           for (int j = 0; j < BF0; ++j) acc[f][j] = mfma32(b0[j][ks], a[f][ks], acc[f][j]);
-      if (STAG) end_mfma(); else end_read(integral_constant<int, DEEP ? D_P1 : W_P1>{});
+      if (STAG) end_mfma(); else if (!grp1) end_read(integral_constant<int, DEEP ? D_P1 : W_P1>{});
 
       // ---- phase 2: quadrant (A0, B1); stage B0 (DEEP: A0 two K-tiles ahead, into the slot phase 1 just read)
       if (DEEP) {
@@ -443,11 +451,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         if (more) issue_b(0, nxt, s_k);
         end_read(integral_constant<int, W_P2>{});
       }
+      if (OFFS && grp1) end_read(integral_constant<int, D_P2>{});
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][BF0] = mfma32(b1[ks], a[f][ks], acc[f][BF0]);
-      if (STAG) end_mfma(); else end_read(integral_constant<int, DEEP ? D_P2 : W_P2>{});
+      if (STAG) end_mfma(); else if (!grp1) end_read(integral_constant<int, DEEP ? D_P2 : W_P2>{});
 
       // ---- phase 3: quadrant (A1, B1); stage B1 (DEEP: B0).  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
       if (DEEP) {
@@ -464,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
       }
+      if (OFFS && grp1) end_read(integral_constant<int, D_P4 - B1_DMA>{});  // B1'' is only issued in phase 4
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         phase_barrier();
       } else {
         if (!DEEP && more) advance_staged();
-        end_read(integral_constant<int, DEEP ? D_P4 : W_P4>{});
+        if (!grp1) end_read(integral_constant<int, DEEP ? D_P4 : W_P4>{});
       }
       credit = false;
       st ^= 1;
@@ -1203,6 +1213,9 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         if (ob)
           hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
+        else if (getenv("PLM_HYB_OFFS") != nullptr)
+          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true, true, false, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                             (int)K, alpha_dev, tm, tn256, rope, h);
         else if (getenv("PLM_HYB_DEEP") != nullptr)
           hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                              (int)K, alpha_dev, tm, tn256, rope, h);
@@ -1234,6 +1247,25 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   }
   static const int p2_max_k = getenv("PLM_GEMM_P2") ? atoi(getenv("PLM_GEMM_P2")) : 0;  // two-phase ring for K <= this (A/B knob)
   const bool env_p2 = K <= p2_max_k;
+  static const bool env_offs = getenv("PLM_GEMM_NO_OFFS") == nullptr;  // default since run 33 (+0.9 % end to end); PLM_GEMM_NO_OFFS=1 for A/B
+  if ((variant >= 16 && variant <= 18) || (variant == 0 && env_offs && !rope_cos)) {  // deep ring with offset wave groups
+    const RopeArgs nr{nullptr, nullptr, 0, 0};
+    int which = variant - 16;  // 0: 256x256, 1: 256x192, 2: 256x128
+    if (variant == 0) which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
+    const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
+    const int nt_ = tm * tn_;
+    const dim3 g(nt_ < slots ? nt_ : slots);
+    if (which == 0)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc,
+                         (int)M, (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    else if (which == 1)
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc,
+                         (int)M, (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    else
+      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc,
+                         (int)M, (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+    return true;
+  }
   if (variant >= 13 && variant <= 15) {  // two-phase deep-prefetch ring: 256x256 / 256x192 / 256x128
     const RopeArgs nr{nullptr, nullptr, 0, 0};
     const int tn_ = variant == 13 ? tn256 : variant == 14 ? tn192 : tn128;
