@@ -94,8 +94,9 @@ int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  * staggered by one barrier, 7 / 8 = 3 / 4 with one barrier per K-tile, 9 = 256x256 with one wave per SIMD,
  * 10 / 11 = 3 / 4 with the deep-prefetch ring (half-tile slots refilled two K-tiles ahead),
  * 12 = persistent 256x192 (64x96 per wave) with the deep-prefetch ring,
- * 13 / 14 / 15 = 10 / 12 / 11 as a two-phase ring (two barriers per K-tile; faster back-to-back, slower in the step)
- * (3..15: bf16 C, no accumulate; 2..15: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
+ * 13 / 14 / 15 = 10 / 12 / 11 as a two-phase ring (two barriers per K-tile; faster back-to-back, slower in the step),
+ * 16 / 17 / 18 = 10 / 12 / 11 with offset wave groups (the automatic choice)
+ * (3..18: bf16 C, no accumulate; 2..18: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
 int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                         void* stream);

@@ -623,7 +623,7 @@ struct TnGroup {
                // split's A / B panels in L2, which the tile-major stream cannot offer); L is then the split length in K-tiles
 };
 
-template <bool DEEP, bool GROUPED = false>
+template <bool DEEP, bool GROUPED = false, bool OFFS = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                              int64_t ldc, float* __restrict__ slabs, int M, int N, int K, int kchunk,
@@ -640,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const bool grp1 = OFFS && (wave >> 2) != 0;  // wave-uniform; waves w and w+4 share a SIMD
   const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
   const int n_full = rfull * tiles_n;
   const int n_rem = tiles_m * tiles_n - n_full;
@@ -830,24 +831,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = tr_frag(cur + OFF_A0, wm * AH + f * 32, ks);
       }
+      auto sync = [&](auto wtag) {
+        if (more) wait_vm<decltype(wtag)::value>(); else wait_vm<0>();
+        phase_barrier();
+      };
+      using WAll = std::integral_constant<int, W_ALL>;
+      if (grp1) sync(WAll{});  // OFFS: the second wave group's barrier sits between the reads and the MFMAs (see gemm_nt_big_kernel)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(a[f][ks], b0[ks], acc[f][0]);
-      if (more) wait_vm<W_ALL>(); else wait_vm<0>();
-      phase_barrier();
+      if (!grp1) sync(WAll{});
 
       if (more) {
         if (DEEP) issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k); else issue(s_bp, pb[0], s_ldb, nxt + OFF_B0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(cur + OFF_B1, wn * 32, ks);
+      if (grp1) sync(WAll{});
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(a[f][ks], b1[ks], acc[f][1]);
-      if (more) wait_vm<W_ALL>(); else wait_vm<0>();
-      phase_barrier();
+      if (!grp1) sync(WAll{});
 
       if (more) {
         if (DEEP) issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k); else issue(s_bp, pb[1], s_ldb, nxt + OFF_B1, s_k);
@@ -856,6 +862,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) a[f][ks] = tr_frag(cur + OFF_A1, wm * AH + f * 32, ks);
+      if (grp1) sync(std::integral_constant<int, W_ALL - 2>{});  // the fourth DMA group of this K-tile is only issued in phase 4
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -868,13 +875,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(a[f][ks], b0[ks], acc[AF + f][0]);
-      if (more) {
-        if (!DEEP) advance_staged();
-        wait_vm<W_ALL>();
-      } else {
-        wait_vm<0>();
+      if (more && !DEEP) advance_staged();
+      if (!grp1) {
+        if (more) wait_vm<W_ALL>(); else wait_vm<0>();
+        phase_barrier();
       }
-      phase_barrier();
       st ^= 1;
     }
 
@@ -957,8 +962,17 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const int nitems = rfull * tn + (tm - rfull) * tn * splits;
   const int slots = persistent_slots();
   const dim3 grid(nitems < slots ? nitems : slots), block(512);
-  static const bool deep = getenv("PLM_TN_DEEP") != nullptr;  // A/B knob: measured equal (run 19), the plain ring stays the default
-  if (!deep)
+  // deep-prefetch ring + offset wave groups (see gemm_nt_big_kernel): each alone measured equal to the plain ring in the step, together
+  // +0.8 % end to end (run 34); PLM_TN_NO_DEEP / PLM_TN_NO_OFFS bring the other forms back for A/B runs
+  static const bool deep = getenv("PLM_TN_NO_DEEP") == nullptr;
+  static const bool offs = getenv("PLM_TN_NO_OFFS") == nullptr;
+  if (offs && !deep)
+    hipLaunchKernelGGL((gemm_tn_big_kernel<false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
+                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
+  else if (offs)
+    hipLaunchKernelGGL((gemm_tn_big_kernel<true, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
+                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
+  else if (!deep)
     hipLaunchKernelGGL((gemm_tn_big_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
                        rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
   else
@@ -1095,8 +1109,16 @@ extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, 
     return PLM_E_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm_tn_big_kernel<false, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
-                     (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
+  static const bool offs = getenv("PLM_TN_NO_OFFS") == nullptr, deep = getenv("PLM_TN_NO_DEEP") == nullptr;
+  if (offs && deep)
+    hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
+                       (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
+  else if (offs)
+    hipLaunchKernelGGL((gemm_tn_big_kernel<false, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
+                       (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
+  else
+    hipLaunchKernelGGL((gemm_tn_big_kernel<false, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
+                       (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
   hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3((unsigned)(g.tile_base[count] * 16)), dim3(256), 0, s, (const float*)workspace, g, o,
                      (int)(K / 64));
   PLM_CHECK_LAUNCH("plm_gemm_bf16_tn_grouped");
