@@ -101,10 +101,10 @@ def cpu_baseline(c, budget_s=28.0):
 
 def pmc_traffic(family, config, tokens, n_layers):
   """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
-  (profiles/r01_pmc_gemm_traffic_run20.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM
+  (profiles/r01_pmc_gemm_traffic_run35.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM
   shape of the 160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the
   profiler on itself, so the figure is the profile's, averaged over the launches of one step; null for other workloads."""
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_run20.json')
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_run35.json')
   if family not in ('gemm_nt', 'gemm_tn') or config != '160m' or tokens != 32768 or not os.path.exists(path):
     return {}
   rows = {r['gemm']: r for r in json.load(open(path))}
@@ -117,7 +117,7 @@ def pmc_traffic(family, config, tokens, n_layers):
   launches = n_layers * len(per_layer) + len(once)
   tot = lambda key: n_layers * sum(rows[g][key] for g in per_layer) + sum(rows[g][key] for g in once)
   return {'traffic': round(tot('traffic_bytes') / launches), 'traffic_unit': 'bytes/launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, Infinity-Cache hits included)',
-          'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': 'profiles/r01_pmc_gemm_traffic_run20.json'}
+          'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': 'profiles/r01_pmc_gemm_traffic_run35.json'}
 
 
 def main():
