@@ -37,6 +37,13 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// vmcnt(flag ? N1 : N0) with a wave-uniform flag: s_waitcnt only takes an immediate, and the if / else form costs hipcc six scalar
+// instructions and two branches per wait (it routes the arms through a mask register)
+template <int N0, int N1>
+__device__ __forceinline__ void wait_vm_sel(int flag) {
+  asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%1)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(%2)\n2:" ::"s"(flag), "n"(N0), "n"(N1)
+               : "memory", "scc");
+}
 // all of this wave's LDS reads have returned, then the workgroup barrier (never drains VMEM)
 __device__ __forceinline__ void phase_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -210,6 +217,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   unsigned oa[2][A_DMA], ob[2][B0_DMA];
   const uint16_t* s_ab = A;
   const uint16_t* s_bb = B;
+  // s_ak / s_bk = s_ab / s_bb + s_k: running pointers of the K-tile under the staging cursor (one 64-bit scalar add per operand
+  // and K-tile instead of a sign-extend + shift + add in front of every DMA pair)
+  const uint16_t* s_ak = A;
+  const uint16_t* s_bk = B;
   auto set_ptrs = [&](int m0, int n0) {
     s_ab = A + (int64_t)m0 * lda;
     s_bb = B + (int64_t)n0 * ldb;
@@ -236,8 +247,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     char* dst = stage + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
-      if (SADDR) dma16_saddr_asm(s_ab + k0, oa[h][i], dst + (i * 8 + wave) * 1024);
-      else big_dma16(reinterpret_cast<const char*>(s_ab + k0) + oa[h][i], dst + (i * 8 + wave) * 1024);  // uniform base + zext(lane offset)
+      (void)k0;
+      if (SADDR) dma16_saddr_asm(s_ak, oa[h][i], dst + (i * 8 + wave) * 1024);
+      else big_dma16(reinterpret_cast<const char*>(s_ak) + oa[h][i], dst + (i * 8 + wave) * 1024);  // uniform base + zext(lane offset)
     }
   };
   auto issue_b = [&](int h, char* stage, int k0) {
@@ -245,8 +257,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < B0_DMA; ++i) {
       if (i >= (h ? B1_DMA : B0_DMA)) continue;
-      if (SADDR) dma16_saddr_asm(s_bb + k0, ob[h][i], dst + (i * 8 + wave) * 1024);
-      else big_dma16(reinterpret_cast<const char*>(s_bb + k0) + ob[h][i], dst + (i * 8 + wave) * 1024);
+      (void)k0;
+      if (SADDR) dma16_saddr_asm(s_bk, ob[h][i], dst + (i * 8 + wave) * 1024);
+      else big_dma16(reinterpret_cast<const char*>(s_bk) + ob[h][i], dst + (i * 8 + wave) * 1024);
     }
   };
   auto frag = [&](const char* ht, int row, int ks) -> bf16x8_t {
@@ -266,11 +279,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       int m0, n0, sp_;
       take(sc, m0, n0, s_k, s_kend, sp_);
       set_ptrs(m0, n0);
+      s_ak = s_ab + s_k;
+      s_bk = s_bb + s_k;
+    } else if (DEEP) {  // nothing left: stay on the last K-tile (DEEP keeps issuing - see `more` in the K loop)
+      s_k -= 64;
+      s_ak -= 64;
+      s_bk -= 64;
     }
   };
   int s_st = 0;  // DEEP: stage buffer of the K-tile under the staging cursor
   auto advance_staged = [&]() {
     s_k += 64;
+    s_ak += 64;
+    s_bk += 64;
     s_st ^= 1;
     if (s_k >= s_kend) open_piece();
   };
@@ -290,14 +311,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     advance_staged();
   }
   if (DEEP) {  // plus A0, B0, B1 of the second K-tile (its A1 follows in phase 1 of the first)
-    if (s_item < ntiles) {
-      issue_a(0, smem + STAGE, s_k);
-      issue_b(0, smem + STAGE, s_k);
-      issue_b(1, smem + STAGE, s_k);
-      wait_vm<P2 ? A_DMA + P_WA : D_P4>();  // P2: phase A reads B1 as well - only A1 and the second K-tile's pieces stay in flight
-    } else {
-      wait_vm<0>();
-    }
+    issue_a(0, smem + STAGE, s_k);
+    issue_b(0, smem + STAGE, s_k);
+    issue_b(1, smem + STAGE, s_k);
+    wait_vm<P2 ? A_DMA + P_WA : D_P4>();  // P2: phase A reads B1 as well - only A1 and the second K-tile's pieces stay in flight
   } else {
     wait_vm<0>();
   }
@@ -306,6 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 
   int st = 0;
   bool credit = false;  // DEEP: NS stores of the previous tile's epilogue are still counted by vmcnt
+  int credit_i = 0;     // the same flag as a scalar register operand of wait_vm_sel
   Cur cc;
   cur_init(cc, first);
   while (cc.item < ntiles) {
@@ -323,7 +341,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
-      bool more = s_item < ntiles;  // workgroup-uniform: the staging cursor still points at a K-tile
+      // workgroup-uniform: the staging cursor still points at a K-tile.  DEEP: constant - when a workgroup runs out of K-tiles it
+      // re-stages its last one into slots nobody reads again (a few KiB of L2 hits per workgroup), so the DMA issue and the
+      // counted waits of the loop carry no conditionals; the loads are drained before the kernel ends.
+      bool more = DEEP || s_item < ntiles;
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[BF0][4], b1[4];
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         if (more) {
           issue_a(1, smem + s_st * STAGE, s_k);
           advance_staged();
-          more = s_item < ntiles;
+          more = DEEP || s_item < ntiles;
         }
         if (more) {
           issue_a(0, smem + s_st * STAGE, s_k);
@@ -377,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
             for (int j = 0; j < BF0; ++j) acc[AF + f][j] = mfma32(b0[j][ks], a[f][ks], acc[AF + f][j]);
           }
         credit = false;
+        credit_i = 0;
         st ^= 1;
         continue;
       }
@@ -385,8 +407,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       auto end_read = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
         if (ONEBAR) return;
+        // one scalar compare on the common path (the nested form cost ~10 scalar instructions and three branches per wait)
         if (!more) wait_vm<0>();
-        else if (DEEP && credit) wait_vm<DEEP ? W + NS : W>();
+        else if (DEEP) wait_vm_sel<W, DEEP ? W + NS : W>(credit_i);
         else wait_vm<W>();
         if (STAG) {  // barrier first: the LDS reads of this section land while the wave waits for the other group
           asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         if (more) {
           issue_a(1, smem + s_st * STAGE, s_k);
           advance_staged();
-          more = s_item < ntiles;
+          more = DEEP || s_item < ntiles;
         }
       } else if (!ONEBAR && !STAG && more) {
         issue_a(0, nxt, s_k);
@@ -507,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         if (!grp1) end_read(integral_constant<int, DEEP ? D_P4 : W_P4>{});
       }
       credit = false;
+      credit_i = 0;
       st ^= 1;
     }
 
@@ -587,7 +611,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       }
     }
     credit = DEEP && m0 + BM <= M && n0 + BN <= N;  // interior tile: every wave issued exactly NS stores
+    credit_i = __builtin_amdgcn_readfirstlane(credit ? 1 : 0);
   }
+  if (DEEP) wait_vm<0>();  // the re-staged tail loads write this workgroup's LDS: they must have landed before the last wave leaves
   if (STAG && !(wm & 1)) phase_barrier();  // balances the extra barrier of the odd group
 }
 
