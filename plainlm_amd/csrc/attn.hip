@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv
   const int cpr = 2 * dm / 8;  // 16-byte chunks of q|k per token row
   const int64_t total = BT * cpr;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  for (int64_t i = PLM_REV_BLOCK() * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t row = i / cpr;
     const int c = (int)(i - row * cpr);
     const int t = (int)(row % T);

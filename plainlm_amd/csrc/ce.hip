@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(uint16_t* __restrict__
                                                           float* __restrict__ loss_rows, int64_t V, int64_t ld,
                                                           float grad_scale) {
   __shared__ MaxSum sh[16];
-  const int64_t row = blockIdx.x;
+  const int64_t row = PLM_REV_BLOCK();
   uint16_t* lr = logits + row * ld;
   const int nvec = (int)(V >> 3);
   const int64_t tgt = targets[row];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_generic_kernel(uint16_t* __re
                                                                   float* __restrict__ loss_rows, int64_t V, int64_t ld,
                                                                   float grad_scale) {
   __shared__ MaxSum sh[16];
-  const int64_t row = blockIdx.x;
+  const int64_t row = PLM_REV_BLOCK();
   bf16_t* lr = reinterpret_cast<bf16_t*>(logits) + row * ld;
   const int64_t tgt = targets[row];
   const bool tgt_ok = tgt >= 0 && tgt < V;

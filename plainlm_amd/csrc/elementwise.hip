@@ -142,8 +142,9 @@ extern "C" int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* ds
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ W,
                                                         float* __restrict__ out, int64_t M, int d, int64_t V) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int64_t row_ = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row_ >= M) return;
+  const int64_t row = PLM_REV_ROW(row_, M);
   int64_t id = ids[row];
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // host validates ids; clamp keeps the kernel memory-safe
   const float* src = W + id * d;
@@ -356,8 +357,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
                                                           uint16_t* __restrict__ y, float* __restrict__ rstd, int64_t M,
                                                           int d, float eps) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int64_t row_ = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row_ >= M) return;
+  const int64_t row = PLM_REV_ROW(row_, M);
   const int nvec = d >> 2;
   const float* xr = x + row * d;
   f32x4_t v[NCH];
@@ -413,7 +415,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __rest
     wv[i] = (c < nvec) ? *reinterpret_cast<const f32x4_t*>(w + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     dwacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row_ = (int64_t)blockIdx.x * 4 + wave; row_ < M; row_ += (int64_t)gridDim.x * 4) {
+    const int64_t row = PLM_REV_ROW(row_, M);
     f32x4_t a[NCH], xv[NCH];
     float dot = 0.f;
     const float r = rstd[row];
@@ -549,7 +552,8 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const uint16_t* __restr
                                                          int64_t h) {
   const int64_t hv = h >> 3, total = M * hv;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int64_t bid = PLM_REV_BLOCK();
+  for (int64_t i = bid * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t m = i / hv, c = (i - m * hv) * 8;
     const bf16x8_t xv = ld_bf16x8(u + m * 2 * h + c);
     const bf16x8_t zv = ld_bf16x8(u + m * 2 * h + h + c);
@@ -568,7 +572,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restr
                                                          uint16_t* __restrict__ du, int64_t M, int64_t h) {
   const int64_t hv = h >> 3, total = M * hv;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int64_t bid = PLM_REV_BLOCK();
+  for (int64_t i = bid * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t m = i / hv, c = (i - m * hv) * 8;
     const bf16x8_t xv = ld_bf16x8(u + m * 2 * h + c);
     const bf16x8_t zv = ld_bf16x8(u + m * 2 * h + h + c);

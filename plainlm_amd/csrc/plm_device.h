@@ -46,6 +46,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define PLM_WAVE 64
 
+// Row order of the HBM-bound kernels: DESCENDING.  The persistent GEMMs walk their tiles in ascending row order, so the rows they
+// wrote last (the ones still in the 256 MB Infinity Cache) are the highest; a consumer that starts there, and that leaves ITS
+// newest output at the low rows where the next GEMM starts, turns the cache into a LIFO between producer and consumer
+// (run 36: swiglu_fwd behind the fc1 GEMM 83 -> 70 us in the step; isolated timings do not change).  -DPLM_EW_FORWARD restores
+// ascending order for A/B builds.
+#ifdef PLM_EW_FORWARD
+#define PLM_REV_BLOCK() ((int64_t)blockIdx.x)
+#define PLM_REV_ROW(row, M) (row)
+#else
+#define PLM_REV_BLOCK() ((int64_t)(gridDim.x - 1 - blockIdx.x))
+#define PLM_REV_ROW(row, M) ((M) - 1 - (row))
+#endif
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32, RNE
 
