@@ -39,6 +39,14 @@ const char* plm_last_error_string(void);
  * copy dst_t[cols, ld_t] (ld_t >= rows; columns rows..ld_t are left untouched) used by the dX GEMMs. */
 int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 int plm_cast_f32_bf16_t(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t rows, int64_t cols, int64_t ld_t, void* stream);
+/* the `_t` cast for a whole list of weights in one launch (every Linear of the model at the top of a step) */
+typedef struct plm_cast_item {
+  const float* src; /* fp32 [rows, cols] */
+  uint16_t* dst;    /* bf16 [rows, cols] */
+  uint16_t* dst_t;  /* bf16 [cols, ld_t], columns 0..rows-1 written */
+  int64_t rows, cols, ld_t;
+} plm_cast_item;
+int plm_cast_f32_bf16_t_multi(const plm_cast_item* items, int count, void* stream);
 
 /* ---- embedding (models/transformer.py:94,110) --------------------------
  * fwd: out[m,:] = W[ids[m],:]           ids int64[M], W fp32[V,d], out fp32[M,d]

@@ -21,6 +21,11 @@ _I = C.c_int
 _F = C.c_float
 _SZ = C.c_size_t
 
+class CastItem(C.Structure):
+  """struct plm_cast_item (include/plainlm_hip.h)."""
+  _fields_ = [('src', _P), ('dst', _P), ('dst_t', _P), ('rows', _I64), ('cols', _I64), ('ld_t', _I64)]
+
+
 class TnProblem(C.Structure):
   """struct plm_tn_problem (include/plainlm_hip.h)."""
   _fields_ = [('A', _P), ('lda', _I64), ('B', _P), ('ldb', _I64), ('C', _P), ('ldc', _I64), ('M', _I64), ('N', _I64),
@@ -33,6 +38,7 @@ SIGNATURES = {
   'plm_last_error_string': (C.c_char_p, []),
   'plm_cast_f32_bf16': (_I, [_P, _P, _I64, _P]),
   'plm_cast_f32_bf16_t': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
+  'plm_cast_f32_bf16_t_multi': (_I, [C.POINTER(CastItem), _I, _P]),
   'plm_embed_fwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_embed_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_embed_bwd_workspace_bytes': (_SZ, [_I64, _I64]),

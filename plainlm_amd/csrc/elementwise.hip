@@ -55,6 +55,86 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_t_kernel(const float* __res
   }
 }
 
+// All stale weight shadows of a model in one launch: the 49 per-Linear casts of the 160M step are launch-latency bound
+// (1 - 6 MB each, 5 - 7 us per launch against ~1 us of traffic).  The item table travels in the kernel arguments.
+#define PLM_CAST_MULTI_MAX 56
+struct CastGroup {
+  const float* src[PLM_CAST_MULTI_MAX];
+  uint16_t* dst[PLM_CAST_MULTI_MAX];
+  uint16_t* dst_t[PLM_CAST_MULTI_MAX];
+  int rows[PLM_CAST_MULTI_MAX], cols[PLM_CAST_MULTI_MAX], ld_t[PLM_CAST_MULTI_MAX];
+  int block_base[PLM_CAST_MULTI_MAX + 1];  // first block of each item; [count] = number of blocks
+  int count;
+};
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_t_multi_kernel(CastGroup g) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+  int it = 0;
+  for (int q = 1; q < g.count; ++q)
+    if ((int)blockIdx.x >= g.block_base[q]) it = q;  // block-uniform scalar search
+  const int local = blockIdx.x - g.block_base[it];
+  const int tiles_x = (g.cols[it] + 63) / 64;
+  const int64_t rows = g.rows[it], cols = g.cols[it], ld_t = g.ld_t[it];
+  const float* __restrict__ src = g.src[it];
+  uint16_t* __restrict__ dst = g.dst[it];
+  uint16_t* __restrict__ dst_t = g.dst_t[it];
+  const int64_t r0 = (int64_t)(local / tiles_x) * 64, c0 = (int64_t)(local % tiles_x) * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+    const int64_t gr = r0 + r, gc = c0 + c;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (gr < rows && gc < cols) v = *reinterpret_cast<const f32x4_t*>(src + gr * cols + gc);
+    bf16x4_t o;
+    o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+    if (gr < rows && gc < cols) st_bf16x4(dst + gr * cols + gc, o);
+    tile[c + 0][r] = o[0]; tile[c + 1][r] = o[1]; tile[c + 2][r] = o[2]; tile[c + 3][r] = o[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (t >> 3) + 32 * i, rch = (t & 7) * 8;
+    const int64_t gc = c0 + c, gr = r0 + rch;
+    if (gc < cols && gr < rows) {
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&tile[c][rch]);
+      st_bf16x8(dst_t + gc * ld_t + gr, v);
+    }
+  }
+}
+
+extern "C" int plm_cast_f32_bf16_t_multi(const plm_cast_item* items, int count, void* stream) {
+  PLM_REQUIRE(items && count >= 1, "plm_cast_f32_bf16_t_multi: null pointer or empty list");
+  for (int first = 0; first < count; first += PLM_CAST_MULTI_MAX) {
+    const int n = count - first < PLM_CAST_MULTI_MAX ? count - first : PLM_CAST_MULTI_MAX;
+    CastGroup g{};
+    int base = 0;
+    for (int i = 0; i < n; ++i) {
+      const plm_cast_item& q = items[first + i];
+      PLM_REQUIRE(q.src && q.dst && q.dst_t, "plm_cast_f32_bf16_t_multi: null pointer in item %d", first + i);
+      PLM_REQUIRE(q.rows > 0 && q.cols > 0 && q.rows % 8 == 0 && q.cols % 8 == 0 && q.rows < (1ll << 31) && q.cols < (1ll << 31),
+                  "plm_cast_f32_bf16_t_multi: item %d: rows=%ld cols=%ld must be positive multiples of 8", first + i, (long)q.rows, (long)q.cols);
+      PLM_REQUIRE(q.ld_t >= q.rows && q.ld_t % 8 == 0 && q.ld_t < (1ll << 31), "plm_cast_f32_bf16_t_multi: item %d: ld_t=%ld must be >= rows and a multiple of 8",
+                  first + i, (long)q.ld_t);
+      g.src[i] = q.src;
+      g.dst[i] = q.dst;
+      g.dst_t[i] = q.dst_t;
+      g.rows[i] = (int)q.rows;
+      g.cols[i] = (int)q.cols;
+      g.ld_t[i] = (int)q.ld_t;
+      g.block_base[i] = base;
+      const int64_t nb = plm_cdiv(q.rows, 64) * plm_cdiv(q.cols, 64);
+      PLM_REQUIRE(base + nb < (1ll << 31), "plm_cast_f32_bf16_t_multi: too many tiles");
+      base += (int)nb;
+    }
+    g.block_base[n] = base;
+    g.count = n;
+    hipLaunchKernelGGL(cast_f32_bf16_t_multi_kernel, dim3((unsigned)base), dim3(256), 0, (hipStream_t)stream, g);
+    PLM_CHECK_LAUNCH("plm_cast_f32_bf16_t_multi");
+  }
+  return PLM_OK;
+}
+
 extern "C" int plm_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
   PLM_REQUIRE(src && dst && n >= 0, "plm_cast_f32_bf16: null pointer or negative n");
   if (n == 0) return PLM_OK;

@@ -82,6 +82,22 @@ def cast_bf16_t(src, out=None, out_t=None):
   return out, out_t
 
 
+def cast_bf16_t_multi(items):
+  """[(src fp32 [R, C], out bf16 [R, C], out_t bf16 [C, >= R])]: cast_bf16_t for all of them in one launch."""
+  if not items:
+    return
+  arr = (_lib.CastItem * len(items))()
+  for i, (src, out, out_t) in enumerate(items):
+    _need(src, F32, 'cast_bf16_t_multi.src', 2)
+    R, Cc = src.shape
+    if out.dtype != BF16 or out.shape != (R, Cc) or not out.is_contiguous() or not out.is_cuda:
+      raise ValueError('cast_bf16_t_multi.out: need contiguous bf16 [R, C] on the GPU')
+    if out_t.dtype != BF16 or out_t.dim() != 2 or out_t.shape[0] != Cc or out_t.shape[1] < R or out_t.stride(1) != 1 or not out_t.is_cuda:
+      raise ValueError('cast_bf16_t_multi.out_t: need bf16 [C, >=R] on the GPU')
+    arr[i] = _lib.CastItem(src.data_ptr(), out.data_ptr(), out_t.data_ptr(), R, Cc, out_t.stride(0))
+  _lib.check(_lib.load().plm_cast_f32_bf16_t_multi(arr, len(items), _stream()), 'plm_cast_f32_bf16_t_multi')
+
+
 # ---- embedding ----------------------------------------------------------------
 def embed_fwd(ids, W):
   _need(ids, torch.int64, 'embed_fwd.ids')

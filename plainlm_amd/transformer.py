@@ -59,16 +59,30 @@ class HipLinear(nn.Module):
     self._shadow = None
     self._shadow_key = None
 
+  def _key(self):
+    w = self.weight
+    return (w.data_ptr(), w._version, w.device)
+
+  def stale_item(self):
+    """None when the shadows are current, else the (src, out, out_t) triple that refreshes them (buffers allocated here);
+    the caller runs the cast and then calls mark_fresh()."""
+    w = self.weight
+    if self._shadow is not None and self._key() == self._shadow_key:
+      return None
+    if self._shadow is None or self._shadow[0].device != w.device:
+      self._shadow = (torch.empty((self.out_features, self.in_features), dtype=torch.bfloat16, device=w.device),
+                      torch.zeros((self.in_features, self.out_pad), dtype=torch.bfloat16, device=w.device))
+    return (w.detach(), self._shadow[0], self._shadow[1])
+
+  def mark_fresh(self):
+    self._shadow_key = self._key()
+
   def shadow(self):
     """(bf16 W [out, in], bf16 W^T [in, out_pad] with zero pad columns), re-cast when the master weight changed."""
-    w = self.weight
-    key = (w.data_ptr(), w._version, w.device)
-    if self._shadow is None or key != self._shadow_key:
-      if self._shadow is None or self._shadow[0].device != w.device:
-        self._shadow = (torch.empty((self.out_features, self.in_features), dtype=torch.bfloat16, device=w.device),
-                        torch.zeros((self.in_features, self.out_pad), dtype=torch.bfloat16, device=w.device))
-      ops.cast_bf16_t(w.detach(), out=self._shadow[0], out_t=self._shadow[1])
-      self._shadow_key = key
+    item = self.stale_item()
+    if item is not None:
+      ops.cast_bf16_t(item[0], out=item[1], out_t=item[2])
+      self.mark_fresh()
     return self._shadow
 
   def invalidate(self):
@@ -194,6 +208,7 @@ class Transformer(nn.Module):
 
     self.sink = Fn.GradSink()
     self._flat_grad = None
+    self._linears = None
     # loss(): token rows per lm_head + cross-entropy chunk (0 = one [M, V] logits buffer)
     self.head_chunk_rows = int(os.environ.get('PLM_HEAD_CHUNK', '0'))
     self.apply(self._init_weights)
@@ -256,6 +271,24 @@ class Transformer(nn.Module):
       if isinstance(m, HipLinear):
         m.invalidate()
 
+  def refresh_shadows(self):
+    """Re-cast every stale bf16 weight shadow in ONE launch (the per-Linear casts are launch-latency bound: 49 launches of
+    1 - 6 MB at the 160M size).  Called at the top of every forward; HipLinear.shadow() stays as the lazy fallback."""
+    if os.environ.get('PLM_NO_MULTI_CAST'):  # A/B knob: back to one cast launch per Linear at its first use
+      return
+    if self._linears is None:
+      seen, self._linears = set(), []
+      for m in self.modules():
+        if isinstance(m, HipLinear) and id(m.weight) not in seen:  # tied weights: one shadow refresh per call site is enough
+          seen.add(id(m.weight))
+          self._linears.append(m)
+    stale = [(m, it) for m in self._linears for it in (m.stale_item(),) if it is not None]
+    if not stale or not stale[0][1][0].is_cuda:
+      return
+    ops.cast_bf16_t_multi([it for _, it in stale])
+    for m, _ in stale:
+      m.mark_fresh()
+
   # ---- forward ---------------------------------------------------------------------
   def _rope(self, device):
     if self._rope_dev is None or self._rope_dev[0].device != device:
@@ -285,6 +318,7 @@ class Transformer(nn.Module):
       raise ValueError(f'sequence length {T} exceeds cfg.seq_len {self.cfg.seq_len}')
     rope = self._rope(x.device)
     doc_start = self._doc_start(attn_mask, B, T)
+    self.refresh_shadows()
     h = self.embed_tokens(x).view(B * T, self.cfg.dim)
     branch = None
     for layer in self.layers:

@@ -509,6 +509,23 @@ def test_cross_entropy_golden(ops, golden_dir):
   assert abs(ref.item() - float(z['ce_loss'])) < 2e-2  # bf16 rounding of the logits only
 
 
+def test_cast_bf16_t_multi(ops):
+  """One launch for a list of weights == the per-weight cast, bit for bit (incl. a padded transposed buffer and > 56 items,
+  which the C side splits into several launches)."""
+  g = torch.Generator().manual_seed(5)
+  shapes = [(2304, 768), (768, 768), (4096, 768), (768, 2048), (50280, 768), (8, 8), (72, 136)] + [(64, 64)] * 60
+  items, want = [], []
+  for R, Cc in shapes:
+    src = torch.randn(R, Cc, generator=g).cuda()
+    pad = -(-R // 64) * 64
+    out, out_t = torch.empty(R, Cc, dtype=torch.bfloat16, device='cuda'), torch.zeros(Cc, pad, dtype=torch.bfloat16, device='cuda')
+    items.append((src, out, out_t))
+    want.append(ops.cast_bf16_t(src, out_t=torch.zeros(Cc, pad, dtype=torch.bfloat16, device='cuda')))
+  ops.cast_bf16_t_multi(items)
+  for (src, out, out_t), (w, wt) in zip(items, want):
+    assert torch.equal(out, w) and torch.equal(out_t, wt), tuple(src.shape)
+
+
 def test_scale_bf16_and_axpy_f32(ops):
   """The two device-scalar passes of the chunked lm_head + cross-entropy backward."""
   g = torch.Generator().manual_seed(11)
