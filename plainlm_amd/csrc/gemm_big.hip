@@ -159,6 +159,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const bool grp1 = OFFS && (wave >> 2) != 0;  // wave-uniform
+  // Waves w and w+4 share a SIMD, and instruction issue is arbitrated by priority, then age: at equal priority the second-dispatched
+  // half (waves 4-7) loses every arbitration.  ONE static s_setprio for that half, no per-phase flips: +1.6 % end to end (run 40).
+#ifndef PLM_NO_PRIO_HALF
+  if (!STAG && wave >= 4) __builtin_amdgcn_s_setprio(1);  // (the staggered schedule flips priorities per section itself)
+#endif
   const int l31 = lane & 31, hi = lane >> 5;
   // HYB = false instantiations keep the plain schedule free of the stream-K bookkeeping
   const int rfull = HYB ? hyb.rfull : tiles_m;
@@ -667,6 +672,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const bool grp1 = OFFS && (wave >> 2) != 0;  // wave-uniform; waves w and w+4 share a SIMD
+#ifndef PLM_NO_PRIO_HALF_TN
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (see gemm_nt_big_kernel)
+#endif
   const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
   const int n_full = rfull * tiles_n;
   const int n_rem = tiles_m * tiles_n - n_full;
