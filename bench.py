@@ -4,6 +4,7 @@ on N MI355X GPUs of one node, one process per GPU.
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...      (no launcher: the parent, which never touches a GPU, starts the N rank processes itself)
 
 A "step" = one fwd+bwd of one micro-batch of 32 x 1024 synthetic tokens per GPU through the fused
 lm_head+cross-entropy loss, including the per-step fp32->bf16 weight casts (what autocast does
@@ -59,10 +60,25 @@ def build_model(c, device, seed=100):
   return model.to(device)
 
 
+def physical_cores():
+  """Distinct (package, core) pairs of /proc/cpuinfo; falls back to os.cpu_count()."""
+  try:
+    seen, phys = set(), None
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('physical id'):
+        phys = line.split(':')[1].strip()
+      elif line.startswith('core id'):
+        seen.add((phys, line.split(':')[1].strip()))
+    return len(seen) or (os.cpu_count() or 1)
+  except OSError:
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(c, budget_s=28.0):
   """Oracle (oracle/cpu_ref.py, fp32 eager) fwd+bwd on the host cores: B=1 sequences of seq_len tokens.
   More threads is not faster for this eager fp32 graph (oversubscription on big hosts), so a few thread counts are
-  tried (one iteration each) and the best one is used for the timed sample; ``cores`` is the count actually used."""
+  tried (one iteration each): ``value`` / ``cores`` are the fastest count's median, ``all_physical_cores`` is the rate
+  with one thread per physical core (SURVEY.md section 8d's definition), reported beside it."""
   from oracle import cpu_ref as O
   ocfg = O.OracleConfig(vocab_size=c['vocab_size'], seq_len=c['seq_len'], dim=c['d_model'], n_layers=c['n_layers'],
                         n_heads=c['n_heads'])
@@ -70,7 +86,7 @@ def cpu_baseline(c, budget_s=28.0):
   rng = np.random.default_rng(1234)
   tok = torch.from_numpy(rng.integers(0, c['vocab_size'], size=(1, c['seq_len'] + 1)))
   ids, tgt = tok[:, :-1], tok[:, 1:]
-  ncpu = os.cpu_count() or 1
+  ncpu, nphys = os.cpu_count() or 1, physical_cores()
   t_all = time.time()
 
   def one():
@@ -80,13 +96,15 @@ def cpu_baseline(c, budget_s=28.0):
 
   default_threads = torch.get_num_threads()
   one()  # warm-up (allocations, thread pool)
-  best_n, best_t = None, None
-  for n in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
-    if time.time() - t_all > 0.5 * budget_s and best_n is not None:
+  torch.set_num_threads(nphys)
+  t_phys = min(one(), one())
+  best_n, best_t = nphys, t_phys
+  for n in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)} - {nphys}):
+    if time.time() - t_all > 0.6 * budget_s:
       break
     torch.set_num_threads(n)
     dt = one()
-    if best_t is None or dt < best_t:
+    if dt < best_t:
       best_n, best_t = n, dt
   torch.set_num_threads(best_n)
   times = [best_t]
@@ -95,19 +113,42 @@ def cpu_baseline(c, budget_s=28.0):
   torch.set_num_threads(default_threads)
   med = float(np.median(times))
   return {'value': round(c['seq_len'] / med, 1), 'unit': 'tokens/s', 'cores': best_n, 'kind': 'port',
+          'all_physical_cores': {'value': round(c['seq_len'] / t_phys, 1), 'cores': nphys},
           'sample': f'oracle/cpu_ref.py fp32 eager fwd+bwd, batch 1 x {c["seq_len"]} tokens, median of {len(times)} iterations '
-                    f'at the fastest of 16/32/64/{ncpu} torch threads (= {best_n}) on a {ncpu}-CPU host'}
+                    f'at the fastest of 16/32/64/{nphys} torch threads (= {best_n}) on a host with {nphys} physical cores / '
+                    f'{ncpu} logical CPUs; all_physical_cores = best of 2 iterations with {nphys} threads'}
+
+
+def csrc_sha():
+  """sha256 over the kernel sources the library is built from (names + contents, sorted): ties a PMC profile to a tree."""
+  import hashlib
+  d = os.path.join(ROOT, 'plainlm_amd', 'csrc')
+  h = hashlib.sha256()
+  for f in sorted(os.listdir(d)):
+    if f.endswith(('.hip', '.h', '.cpp')) or f == 'Makefile':
+      h.update(f.encode())
+      h.update(open(os.path.join(d, f), 'rb').read())
+  return h.hexdigest()[:16]
+
+
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_pmc_gemm_traffic.json')
 
 
 def pmc_traffic(family, config, tokens, n_layers):
   """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
-  (profiles/r01_pmc_gemm_traffic_run35.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM
-  shape of the 160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the
-  profiler on itself, so the figure is the profile's, averaged over the launches of one step; null for other workloads."""
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_run35.json')
-  if family not in ('gemm_nt', 'gemm_tn') or config != '160m' or tokens != 32768 or not os.path.exists(path):
+  (profiles/r02_pmc_gemm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM shape of the
+  160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the profiler on
+  itself, so the figure is the profile's, averaged over the launches of one step - and ONLY when the profile was taken on
+  this very tree (the profile records the sha of plainlm_amd/csrc): otherwise traffic stays null and the reason is stated."""
+  if family not in ('gemm_nt', 'gemm_tn') or config != '160m' or tokens != 32768:
     return {}
-  rows = {r['gemm']: r for r in json.load(open(path))}
+  if not os.path.exists(PMC_PROFILE):
+    return {'traffic_note': 'no PMC profile committed for this workload'}
+  prof = json.load(open(PMC_PROFILE))
+  if prof.get('csrc_sha') != csrc_sha():
+    return {'traffic_note': f'profiles/{os.path.basename(PMC_PROFILE)} was taken on csrc {prof.get("csrc_sha")}, this tree is '
+                            f'{csrc_sha()}: not reported'}
+  rows = {r['gemm']: r for r in prof['rows']}
   if family == 'gemm_nt':  # per layer: 4 forward + 4 dX projections (dX out has the out-fwd shape); plus lm_head fwd and dX
     per_layer = ['nt qkv fwd', 'nt out fwd', 'nt fc1 fwd', 'nt fc2 fwd', 'nt dX qkv', 'nt out fwd', 'nt dX fc1', 'nt dX fc2']
     once = ['nt head fwd', 'nt dX head']
@@ -117,7 +158,43 @@ def pmc_traffic(family, config, tokens, n_layers):
   launches = n_layers * len(per_layer) + len(once)
   tot = lambda key: n_layers * sum(rows[g][key] for g in per_layer) + sum(rows[g][key] for g in once)
   return {'traffic': round(tot('traffic_bytes') / launches), 'traffic_unit': 'bytes/launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, Infinity-Cache hits included)',
-          'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': 'profiles/r01_pmc_gemm_traffic_run35.json'}
+          'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': f'profiles/{os.path.basename(PMC_PROFILE)}',
+          'csrc_sha': prof['csrc_sha']}
+
+
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) as children with the
+  torch.distributed.run environment and hand back the worst exit code.  The parent never initialises HIP (importing torch
+  does not), and no process that has is ever re-exec'ed."""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PLM_BENCH_CHILD='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+  rc = 0
+  try:
+    while procs:
+      for p in list(procs):
+        code = p.poll()
+        if code is None:
+          continue
+        procs.remove(p)
+        if code != 0:  # one rank died: the others would wait in a collective forever
+          rc = rc or code
+          for q in procs:
+            q.terminate()
+      time.sleep(0.2)
+  finally:
+    for q in procs:
+      q.kill()
+  return rc
 
 
 def main():
@@ -134,6 +211,8 @@ def main():
                   help='BASELINE configs[4]: document-boundary attention masks (random documents, mean length ~256)')
   a = ap.parse_args()
 
+  if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    raise SystemExit(spawn_ranks(a.gpus))
   rank = int(os.environ.get('RANK', 0))
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))
@@ -164,7 +243,7 @@ def main():
   if world > 1 or force_reducer:
     comm = ddp.make_comm(device, a.comm)
     reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
-                              reserve_cus=ddp.COMM_CUS if force_reducer else None)
+                              reserve_cus=ddp.COMM_CUS if force_reducer else None, writers=model.grad_writers())
     reducer.broadcast_params([p.data for p in params])
     model.sink.on_ready = reducer.param_ready
 
@@ -238,6 +317,10 @@ def main():
     'mfu_bf16': round(value / world * fpt / (PEAK_BF16_TFLOPS * 1e12), 4),
     'flops_per_token': fpt, 'loss': round(last_loss, 4),
   }
+  if reducer is not None:  # which data plane actually ran (make_comm may fall back from direct RCCL to torch's nccl backend)
+    out['comm'] = {'backend': reducer.comm.backend, 'ranks': reducer.comm.world_size, 'buckets': len(reducer.buckets),
+                   'bucket_cap_mb': a.bucket_mb, 'cu_reserve': reducer.reserve_cus,
+                   'nccl_max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS')}
 
   if not a.no_extras:
     # ---- roofline leg: identical steps with HIP events around every MFMA kernel launch (untimed) ----
@@ -270,7 +353,7 @@ def main():
       opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
       if reducer is not None:
         reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
-                                  reserve_cus=reducer.reserve_cus)
+                                  reserve_cus=reducer.reserve_cus, writers=model.grad_writers())
         model.sink.on_ready = reducer.param_ready
 
       def full(i):

@@ -298,7 +298,7 @@ class OracleEngine:
     tgt = batch['input_ids'][:, 1:T + 1]
     ds = doc_start_from_lengths(batch['docs_lengths'], T) if self.intra_doc_masking else None
     self.accumulated += 1
-    loss, g = loss_and_grads(self.params, self.cfg, ids, tgt, ds, scale=1.0 / self.accum)
+    loss, g = self._loss_and_grads(ids, tgt, ds)
     if self.grads is None:
       self.grads = g
     else:
@@ -308,6 +308,10 @@ class OracleEngine:
       self.accumulated = 0
       self._optimizer_step()
     return loss
+
+  def _loss_and_grads(self, ids, tgt, ds):
+    """fwd+bwd of one micro-batch with the 1/accum factor of engine.py:118 (overridden by the bf16-emulating mode)."""
+    return loss_and_grads(self.params, self.cfg, ids, tgt, ds, scale=1.0 / self.accum)
 
   def _optimizer_step(self):
     g = self.grads

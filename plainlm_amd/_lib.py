@@ -15,6 +15,10 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'plainlm_hip.h')
 
 _lib = None
 
+# ABI the signatures below were written for (plm_version() of the library must match: a stale .so that still exports every
+# symbol but with other argument lists / struct layouts would corrupt memory instead of raising)
+EXPECTED_ABI = 102
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I = C.c_int
@@ -99,6 +103,10 @@ def load():
     fn = getattr(lib, name)  # AttributeError -> symbol missing, loud by construction
     fn.restype = res
     fn.argtypes = args
+  got = lib.plm_version()
+  if got != EXPECTED_ABI:
+    raise RuntimeError(f'{LIB_PATH} reports ABI version {got}, this package was written for {EXPECTED_ABI}: '
+                       'rebuild it (make -C plainlm_amd/csrc)')
   _lib = lib
   return lib
 

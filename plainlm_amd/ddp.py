@@ -27,27 +27,45 @@ from . import _lib
 # finish(), so the forward pass and the lm_head backward (no collective in flight) keep all 256 CUs (the reserve costs
 # 5.5 % on the GEMMs it applies to, run 30).
 COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+  # RCCL reads this when the FIRST communicator of the process is created - which may be torch.distributed's own
+  # (init_process_group('nccl') in a reference-style train.py) - so it is set when this module is imported, not only when
+  # our communicator is built.
+  os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
 
 
 class RcclComm:
-  """Direct RCCL communicator (one per process = one per GPU)."""
+  """Direct RCCL communicator (one per process = one per GPU).
+
+  Creation is collective.  The unique id is exchanged over the already-initialised control-plane group; rank 0 ALWAYS takes
+  part in that broadcast (it ships ``None`` when ncclGetUniqueId failed), so a failure before ncclCommInitRank raises on
+  every rank together and make_comm's fallback stays in step.  A failure INSIDE ncclCommInitRank on a subset of the ranks is
+  not recoverable (the others block in it) - that is RCCL's contract, not ours."""
 
   def __init__(self, rank, world_size, device_index, store_group=None):
     if world_size > 1:
       os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
     lib = _lib.load()
-    uid = (C.c_uint8 * 128)()
+    uid, err = (C.c_uint8 * 128)(), None
     if rank == 0:
-      _lib.check(lib.plm_comm_unique_id(C.cast(uid, C.c_void_p)), 'plm_comm_unique_id')
+      try:
+        _lib.check(lib.plm_comm_unique_id(C.cast(uid, C.c_void_p)), 'plm_comm_unique_id')
+      except RuntimeError as e:
+        err = e
     if world_size > 1:
-      # ship the 128-byte id over the already-initialised control-plane group (gloo or nccl)
-      obj = [bytes(uid)] if rank == 0 else [None]
+      # ship the 128-byte id over the control-plane group (gloo or nccl); None = rank 0 has no id
+      obj = [bytes(uid) if err is None else None] if rank == 0 else [None]
       dist.broadcast_object_list(obj, src=0, group=store_group)
+      if obj[0] is None:
+        raise err if err is not None else RuntimeError('rank 0 could not create an RCCL unique id')
       uid = (C.c_uint8 * 128).from_buffer_copy(obj[0])
+    elif err is not None:
+      raise err
     handle = C.c_void_p()
     _lib.check(lib.plm_comm_init(C.byref(handle), C.cast(uid, C.c_void_p), rank, world_size, device_index), 'plm_comm_init')
     self.handle, self.lib = handle, lib
     self.rank, self.world_size = rank, world_size
+    self.backend = 'rccl-direct'
 
   def allreduce_avg_(self, span, stream):
     _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),
@@ -70,6 +88,7 @@ class TorchDistComm:
     self.group = group
     self.rank = dist.get_rank(group)
     self.world_size = dist.get_world_size(group)
+    self.backend = 'torch-' + dist.get_backend(group)
 
   def allreduce_avg_(self, span, stream=None):
     if dist.get_backend(self.group) == 'gloo':  # gloo has no AVG
@@ -118,11 +137,19 @@ class GradReducer:
       reducer.finish()                           # after backward, before clip/optimizer
   """
 
-  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False, reserve_cus=None):
+  def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False, reserve_cus=None,
+               writers=None):
+    """writers: optional {id(param): n} = how many backward kernels write that parameter's gradient per backward pass
+    (default 1).  A weight shared by lm_head and embed_tokens (tie_embeddings, models/transformer.py:131-132) has two: the
+    head's dW first, the embedding scatter last.  A bucket is launched only when every writer of every member has
+    reported; launching after the first would let RCCL reduce the span in place while the second kernel still adds to it."""
     self.flat = flat_grad
     self.comm = comm
     self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)))
     self.index_of = {id(p): i for i, p in enumerate(params)}
+    self.writers = [int((writers or {}).get(id(p), 1)) for p in params]
+    if min(self.writers, default=1) < 1:
+      raise ValueError('GradReducer: every parameter needs at least one gradient writer')
     self.bucket_of = {}
     for b, (_, _, idxs) in enumerate(self.buckets):
       for i in idxs:
@@ -142,7 +169,7 @@ class GradReducer:
 
   def begin(self, sync):
     self.sync = bool(sync) and (self.comm.world_size > 1 or self.force)
-    self.pending = [len(idxs) for (_, _, idxs) in self.buckets]
+    self.pending = [sum(self.writers[i] for i in idxs) for (_, _, idxs) in self.buckets]
     self.launched = []
 
   def _launch(self, b):
@@ -170,6 +197,9 @@ class GradReducer:
       return
     b = self.bucket_of[i]
     self.pending[b] -= 1
+    if self.pending[b] < 0:
+      raise RuntimeError(f'GradReducer: parameter {i} reported more gradient writes than declared ({self.writers[i]}); '
+                         'a shared weight needs writers={id(p): n}')
     if self.pending[b] == 0 and self.overlap:
       self._launch(b)
 

@@ -171,9 +171,12 @@ class HipEngine(torch.nn.Module):
     self.intra_doc_masking = getattr(cfg, 'intra_doc_masking', False)
     self.device = device
     self._stager = _Stager()
-    # 'Train loss is nan' (engine.py:116-117) is raised for micro-step k when step k + nan_check_lag is submitted (or by
-    # check_losses()), so the host never waits for the micro-step it has just enqueued; 0 = the reference's immediate sync
-    self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 2))
+    # 'Train loss is nan' (engine.py:116-117).  Default 0 = the reference's semantics: the flag of micro-step k is read
+    # (one pinned byte, its own event) before k's backward is enqueued.  nan_check_lag = n > 0 (opt-in) defers the read to the
+    # submission of micro-step k + n so the host never waits inside an accumulation window; the window's LAST micro-step
+    # always drains every outstanding flag before clip + AdamW, so an update computed from a NaN loss is never applied and
+    # no micro-step of a run goes unchecked.
+    self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 0))
     self._unchecked, self._flag_pool = [], []
     if self.dtype != 'bfloat16':
       raise NotImplementedError(f"dtype '{self.dtype}': the gfx950 kernels implement the bfloat16 flow only")
@@ -197,7 +200,8 @@ class HipEngine(torch.nn.Module):
     self.reducer = None
     if dist.is_initialized() and dist.get_world_size() > 1:
       comm = ddp.make_comm(device, comm_backend)
-      self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb)
+      self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb,
+                                      writers=self.model.grad_writers())
       self.reducer.broadcast_params([p.data for p in self.params])  # DDP ctor's _sync_module_states
       self.model.invalidate_shadows()
       self.model.sink.on_ready = self.reducer.param_ready
@@ -229,6 +233,7 @@ class HipEngine(torch.nn.Module):
 
     if last:
       self.accumulated_samples = 0
+      self.check_losses()  # lag > 0: no optimizer update from a window that contains a NaN loss
       if hasattr(self.optimizer, 'clip_and_step'):
         self.optimizer.clip_and_step(self.grad_clip or None)  # fused global-norm clip + AdamW on the flat buffers
       else:

@@ -260,6 +260,15 @@ class Transformer(nn.Module):
     self.sink.enabled = True
     return self._flat_grad
 
+  def grad_writers(self):
+    """{id(param): number of backward kernels that write its gradient in one backward pass}: 1 per owning module, so 2
+    for a weight tied between lm_head and embed_tokens.  ddp.GradReducer launches a bucket when all writers have reported."""
+    n = {}
+    for m in self.modules():
+      if isinstance(m, (HipLinear, HipEmbedding, RMSNorm)):
+        n[id(m.weight)] = n.get(id(m.weight), 0) + 1
+    return n
+
   def attach_grads(self):
     """Expose the flat buffer through ``p.grad`` for optimizers / clipping."""
     self.sink.flush_dw()

@@ -231,8 +231,48 @@ def main():
   report('engine final out_norm', oe.params['out_norm.weight'], final['out_norm.weight'])
   print('losses', np.round(losses, 5))
   print('lrs', lrs)
-  for f in ('ops.npz', 'model.npz', 'engine.npz'):
+  make_checkpoint_fixture(construct_model, TorchEngine, rng)
+  for f in ('ops.npz', 'model.npz', 'engine.npz', 'ckpt.npz', 'ref_ckpt_step_2.pth'):
     print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
+
+
+CKPT_CFG = dict(model='transformer', vocab_size=128, seq_len=32, d_model=64, expand='8/3', n_layers=2, n_heads=1,
+                mlp_class='glu', tie_embeddings=False, torch_compile=False, micro_batch_size=1,
+                grad_accumulation_steps=2, dtype='bfloat16', optim='adamw', fused_optim=False, lr=3e-3,
+                weight_decay=0.1, beta1=0.9, beta2=0.95, grad_clip=1.0, scheduler='warmup_cosine', warmup_steps=2,
+                cooldown_steps=None, lr_start=0.0, lr_end=1e-5, lr_end_pct=None, steps_budget=8, resume=False, seed=100)
+
+
+def make_checkpoint_fixture(construct_model, TorchEngine, rng):
+  """a checkpoint WRITTEN BY THE REFERENCE engine (the dict of checkpoint_utils.py:32-38, saved with
+  torch.save like :45) after 2 optimizer steps of a small model, plus what the reference does next: the losses of the
+  following 2 optimizer steps when it resumes from that file (engine/engine.py:56-60,86-89).  ckpt.npz also carries the
+  initial weights and every batch, so the GPU test can run the first two steps itself and write ITS checkpoint."""
+  ecfg = namedtuple('Config', CKPT_CFG.keys())(**CKPT_CFG)
+  torch.manual_seed(100)
+  model, _ = construct_model(ecfg)
+  init = {n: p.detach().clone() for n, p in model.named_parameters()}
+  eng = TorchEngine(model, ecfg, 'cpu', None, None)
+  tok = torch.from_numpy(rng.integers(0, CKPT_CFG['vocab_size'], size=(8, 1, CKPT_CFG['seq_len'] + 1)))
+  losses = [eng.step({'input_ids': tok[i]}).item() for i in range(4)]
+  state = {'step': 2, 'state_dict': model.state_dict(), 'optimizer': eng.optimizer.state_dict(),
+           'scheduler': eng.scheduler.state_dict(), 'scaler': eng.scaler.state_dict()}
+  path = os.path.join(HERE, 'ref_ckpt_step_2.pth')
+  torch.save(state, path)
+  # resume exactly as train.py does: fresh model, cfg.resume = True, checkpoint loaded on the CPU
+  rcfg = namedtuple('Config', CKPT_CFG.keys())(**dict(CKPT_CFG, resume=True))
+  model2, _ = construct_model(rcfg)
+  eng2 = TorchEngine(model2, rcfg, 'cpu', None, torch.load(path, map_location='cpu', weights_only=False))
+  assert eng2.micro_steps == 4
+  resumed = [eng2.step({'input_ids': tok[i]}).item() for i in range(4, 8)]
+  cont = [eng.step({'input_ids': tok[i]}).item() for i in range(4, 8)]  # the uninterrupted run, for reference
+  assert np.allclose(resumed, cont, rtol=1e-6), (resumed, cont)
+  out = {'tokens': tok, 'losses': np.array(losses + resumed), 'lr_after': np.array(eng2.optimizer.param_groups[0]['lr']),
+         'sched_iter': np.array(eng2.scheduler.iter)}
+  out.update({'w:' + n: v for n, v in init.items()})
+  out.update({'final:' + n: p.detach().clone() for n, p in model2.named_parameters() if 'norm' in n or n.endswith('w_out.weight')})
+  np.savez_compressed(os.path.join(HERE, 'ckpt.npz'), **{k: np.asarray(v) for k, v in out.items()})
+  print('checkpoint fixture: losses', np.round(losses + resumed, 5), 'scheduler', eng2.scheduler.state_dict())
 
 
 if __name__ == '__main__':

@@ -25,11 +25,11 @@ def _free_port():
     return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, tied=False):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
   dist.init_process_group('gloo', rank=rank, world_size=world)
   torch.set_num_threads(1)
-  ocfg = O.OracleConfig(**CFG)
+  ocfg = O.OracleConfig(**CFG, tie_embeddings=tied)
   names = O.param_names(ocfg)
   shapes = O.param_shapes(ocfg)
   # rank-dependent init, then broadcast from rank 0 (DDP ctor semantics)
@@ -43,7 +43,10 @@ def _worker(rank, world, port, out_dir):
   flat_g = torch.zeros(off)
   plist = [flat_p[o:o + k] for o, k in spans]
   comm = ddp.make_comm('cpu', 'torch')
-  red = ddp.GradReducer(flat_g, plist, spans, comm, bucket_cap_mb=0.01)  # ~2.6k floats per bucket: many buckets
+  # tied embeddings: the shared weight (parameter 0) is written twice per backward - lm_head's dW first, the embedding
+  # scatter last (functional.HeadLossFn / EmbedFn) - and its bucket may only go out after the second write
+  writers = {id(plist[0]): 2} if tied else None
+  red = ddp.GradReducer(flat_g, plist, spans, comm, bucket_cap_mb=0.01, writers=writers)  # ~2.6k floats per bucket: many buckets
   assert len(red.buckets) > 3
   red.broadcast_params(flat_p)
   params = {n: flat_p[o:o + k].view(shapes[n]) for n, (o, k) in zip(names, spans)}
@@ -63,10 +66,21 @@ def _worker(rank, world, port, out_dir):
     batch = tok[micro * world + rank]  # rows r, r+W, ... of each micro-step
     _, g = O.loss_and_grads(params, ocfg, batch[:, :-1], batch[:, 1:], scale=1.0 / accum)
     red.begin(sync=(micro == accum - 1))
+    if tied:  # the head's share of the shared weight's gradient comes first in backward
+      o, k = spans[0]
+      half = 0.5 * g[names[0]].reshape(-1)
+      if micro == 0:
+        flat_g[o:o + k] = half
+      else:
+        flat_g[o:o + k] += half
+      red.param_ready(plist[0])
+      assert calls['n'] == 0  # one of two writers has reported: the bucket must not be reduced yet
     # gradients become ready last-parameter-first, like backward
     for i in range(len(names) - 1, -1, -1):
       o, k = spans[i]
-      if micro == 0:
+      if tied and i == 0:
+        flat_g[o:o + k] += half
+      elif micro == 0:
         flat_g[o:o + k] = g[names[i]].reshape(-1)
       else:
         flat_g[o:o + k] += g[names[i]].reshape(-1)
@@ -75,6 +89,12 @@ def _worker(rank, world, port, out_dir):
       assert calls['n'] == 0  # no communication on non-final accumulation micro-steps
     red.finish()
   assert calls['n'] == len(red.buckets)
+  if tied:  # a third report for a parameter with two declared writers is a wiring bug and must be loud
+    red.begin(sync=True)
+    red.param_ready(plist[0]); red.param_ready(plist[0])
+    with pytest.raises(RuntimeError, match='more gradient writes'):
+      red.param_ready(plist[0])
+    red.sync = False
   # collective agreement used by make_comm's RCCL -> torch fallback: one failing rank makes every rank fall back
   assert ddp.all_ranks_ok(True) is True
   assert ddp.all_ranks_ok(rank != 1) is False
@@ -84,15 +104,16 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_bucketed_allreduce_equals_accumulation(tmp_path):
+@pytest.mark.parametrize('tied', [False, True])
+def test_two_rank_bucketed_allreduce_equals_accumulation(tmp_path, tied):
   world = 2
-  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), tied), nprocs=world, join=True)
   r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
   # (ii) identical params and reduced grads on every rank
   assert torch.equal(r[0]['params'], r[1]['params'])
   assert torch.equal(r[0]['grads'], r[1]['grads'])
   # (i)+(iii) single process, accumulation over all W*accum micro-batches, one flat mean
-  ocfg = O.OracleConfig(**CFG)
+  ocfg = O.OracleConfig(**CFG, tie_embeddings=tied)
   names = O.param_names(ocfg)
   params = O.init_params(ocfg, seed=0)  # rank 0's init was broadcast
   assert torch.equal(r[0]['params'], torch.cat([params[n].reshape(-1) for n in names]))

@@ -208,7 +208,7 @@ def test_gemm_nt(ops, M, N, K):
   close(acc, 1 + 0.5 * ref, 2e-5 * math.sqrt(K), 'gemm_nt accumulate/alpha')
 
 
-@pytest.mark.parametrize('variant', [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize('variant', [2, 3, 16, 17, 18])  # 128x128 LDS-DMA, the plain 256x256 schedule, and the three tiles of the automatic policy's deep ring
 @pytest.mark.parametrize('M,N,K', [(512, 512, 64), (1000, 392, 192), (2048, 768, 768), (8192, 2304, 128), (300, 136, 64),
                                    (33000, 768, 64), (32768, 768, 2304)])
 def test_gemm_nt_variants(ops, M, N, K, variant):

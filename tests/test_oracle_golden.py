@@ -167,3 +167,52 @@ def test_engine_loss_sequence(mdl, golden_dir):
   _close(eng.params['layers.1.mlp.fc2.weight'], en['final:layers.1.mlp.fc2.weight'], 5e-5)
   _close(eng.params['out_norm.weight'], en['final:out_norm.weight'], 5e-6)
   _close(eng.params['embed_tokens.weight'][:16], en['final:embed_rows'], 5e-5)
+
+
+# ---- bf16-emulating mode (oracle/cpu_ref_bf16.py) ----------------------------------------------------------------------
+def test_bf16_mode_without_rounding_equals_fp32_oracle(mdl):
+  """The hand-written forward + backward of the emulating mode IS the reference's algorithm: with the bf16 rounding
+  switched off it reproduces the golden loss and all 15 gradients of the reference model (causal and document-masked),
+  and the tied-embedding variant of the fp32 oracle."""
+  from oracle import cpu_ref_bf16 as E
+  cfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2)
+  w = {k[2:]: v for k, v in mdl.items() if k.startswith('w:')}
+  tok = mdl['tokens']
+  ids, tgt = tok[:, :64], tok[:, 1:65]
+  loss, g = E.loss_and_grads(w, cfg, ids, tgt, round_bf16=False)
+  _close(loss, mdl['loss'])
+  for n in w:
+    _close(g[n], mdl['g:' + n], 5e-6)
+  ds = O.doc_start_from_lengths(_docs(mdl, 'docs_lengths'), 64)
+  l0, g0 = O.loss_and_grads(w, cfg, ids, tgt, ds, scale=0.25)
+  l1, g1 = E.loss_and_grads(w, cfg, ids, tgt, ds, scale=0.25, round_bf16=False)
+  _close(l1, l0)
+  for n in w:
+    _close(g1[n], g0[n], 5e-6)
+  tcfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2, tie_embeddings=True)
+  tw = {k: v for k, v in w.items() if k != 'lm_head.weight'}
+  l0, g0 = O.loss_and_grads(tw, tcfg, ids, tgt)
+  l1, g1 = E.loss_and_grads(tw, tcfg, ids, tgt, round_bf16=False)
+  _close(l1, l0)
+  for n in tw:
+    _close(g1[n], g0[n], 5e-6)
+
+
+def test_bf16_mode_engine_tracks_the_reference_trajectory(mdl, golden_dir):
+  """What bf16 rounding ALONE does to the reference's 16-micro-step trajectory (4 optimizer steps, the last three with
+  lr > 0): the emulated bf16 flow stays within 1e-4 of the reference engine's own fp32 losses on every micro-step, before
+  and after real parameter updates - so 1e-4 is a fair bar for the HIP engine on all 16 steps, and a kernel that is off by
+  1e-3 cannot hide behind 'bf16 drift' (the GPU test asserts exactly this)."""
+  from oracle import cpu_ref_bf16 as E
+  en = np.load(os.path.join(golden_dir, 'engine.npz'))
+  cfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2)
+  w = {k[2:]: v for k, v in mdl.items() if k.startswith('w:')}
+  tokens = torch.from_numpy(en['tokens'])
+  kw = dict(lr=3e-3, weight_decay=0.1, beta1=0.9, beta2=0.95, grad_clip=1.0, accum=4, steps_budget=8, warmup_steps=2)
+  emu = E.OracleEngineBF16(w, cfg, **kw)
+  exact = E.OracleEngineBF16(w, cfg, round_bf16=False, **kw)
+  le = np.array([emu.step({'input_ids': tokens[i]}).item() for i in range(16)])
+  lx = np.array([exact.step({'input_ids': tokens[i]}).item() for i in range(16)])
+  assert (np.abs(lx - en['losses']) / en['losses']).max() <= 2e-6
+  rel = np.abs(le - en['losses']) / en['losses']
+  assert 1e-7 < rel.max() <= 1e-4, rel  # rounding is on (non-zero) and harmless (<= 1e-4), also after the updates
