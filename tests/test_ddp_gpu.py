@@ -121,7 +121,11 @@ def test_two_rank_engine_equals_accumulation(tmp_path, tied):
   lr = 3e-3
   for n, p in eng.model.named_parameters():
     diff = (many[0]['params'][n] - p.detach().cpu()).abs()
-    # AdamW normalises every element's update to ~lr, so a gradient that is ~0 can flip its direction on a last-bit
-    # difference between (a + b) / 2 and sequential accumulation; such elements are rare, everything else agrees to fp32
-    assert (diff > 1e-6 + 1e-4 * lr).float().mean().item() < 5e-3, n
+    # (a + b) / 2 across ranks vs sequential accumulation differ in the last fp32 bits; where the micro-batch gradients of
+    # an element nearly cancel that is a large RELATIVE change of a tiny gradient, and AdamW normalises every element's
+    # update to ~lr whatever its gradient's size.  So: typical elements agree to fp32, a few move by a fraction of lr,
+    # none by more than a sign flip on each of the two updates.
+    assert diff.median().item() <= 1e-7, n
+    assert (diff > 0.02 * lr).float().mean().item() < 0.01, n
+    assert diff.pow(2).mean().sqrt().item() < 0.02 * lr, n
     assert diff.max().item() <= 2.5 * 2 * lr, n

@@ -333,13 +333,15 @@ def test_engine_docmask_and_errors(P, mdl):
 
 
 def test_engine_nan_check_and_staging(P, mdl):
-  """engine.py:116-117: a NaN loss raises ValueError - deferred by `nan_check_lag` micro-steps (default 2) so that the host
-  never syncs on the step it has just submitted; `check_losses()` / lag 0 give the reference's immediate behaviour.
+  """engine.py:116-117: a NaN loss raises ValueError BEFORE its backward is enqueued (default, the reference's order).
+  With the opt-in ``nan_check_lag`` the flag is read later - but always before the optimizer step of the window, so a NaN
+  loss never reaches the weights or the AdamW moments, and no micro-step goes unchecked.
   Also: the pinned staging ring hands over the same tokens as a plain copy."""
   cfg = _engine_cfg(grad_accumulation_steps=1)
   model, _ = P.construct_model(cfg)
   model.load_state_dict(_weights(mdl))
   eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  assert eng.nan_check_lag == 0
   tok = mdl['tokens']
   from plainlm_amd.engine import _move_to_device, _Stager
   st = _Stager(depth=2)
@@ -348,15 +350,29 @@ def test_engine_nan_check_and_staging(P, mdl):
     assert torch.equal(ids.cpu(), tok[:, :64]) and torch.equal(tgt.cpu(), tok[:, 1:65])
   ok = eng.step({'input_ids': tok})
   assert torch.isfinite(ok)
+  steps_before = eng.optimizer._step_count
   with torch.no_grad():
     eng.model.out_norm.weight.fill_(float('nan'))
   eng.model.invalidate_shadows()
-  eng.step({'input_ids': tok})  # NaN loss submitted, not yet checked
   with pytest.raises(ValueError, match='Train loss is nan'):
-    eng.check_losses()
-  eng2 = P.TorchEngine(model, _engine_cfg(grad_accumulation_steps=1, nan_check_lag=0), 'cuda', None, None)
+    eng.step({'input_ids': tok})
+  assert eng.optimizer._step_count == steps_before and torch.isfinite(eng.optimizer.flat_m).all()
+  # opt-in lag: micro-step 1 of a 2-step window submits a NaN loss and returns; the window's last micro-step drains the
+  # flags before clip + AdamW
+  model2, _ = P.construct_model(cfg)
+  model2.load_state_dict(_weights(mdl))
+  eng2 = P.TorchEngine(model2, _engine_cfg(grad_accumulation_steps=2, nan_check_lag=2), 'cuda', None, None)
+  with torch.no_grad():
+    eng2.model.out_norm.weight.fill_(float('nan'))
+  eng2.model.invalidate_shadows()
+  eng2.step({'input_ids': tok})  # submitted, not yet checked
   with pytest.raises(ValueError, match='Train loss is nan'):
     eng2.step({'input_ids': tok})
+  assert eng2.optimizer._step_count == 0 and torch.isfinite(eng2.optimizer.flat_m).all()
+  eng3 = P.TorchEngine(model, _engine_cfg(grad_accumulation_steps=4, nan_check_lag=2), 'cuda', None, None)
+  eng3.step({'input_ids': tok})
+  with pytest.raises(ValueError, match='Train loss is nan'):
+    eng3.check_losses()
 
 
 CKPT_CFG = dict(vocab_size=128, seq_len=32, d_model=64, n_layers=2, n_heads=1, grad_accumulation_steps=2)

@@ -1,0 +1,95 @@
+"""Launch every MFMA kernel of the 160M step twice (warm + measured) in a fixed order, for rocprofv3 --pmc passes.
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o f --output-format csv -- python3 tools/prof_kernels.py
+  rocprofv3 --pmc WRITE_SIZE ...                                              (separate pass: TCC slots)
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE ... (MFMA utilisation)
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT ...
+
+The program prints one line ``ORDER <json>``: the csrc sha of the tree and the launch list (name, kernel-name substring,
+shape, algorithmic bytes / flops).  tools/pmc_report.py joins it with the counter CSVs by dispatch order."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import csrc_sha  # noqa: E402
+from plainlm_amd import _lib, ops  # noqa: E402
+
+BF = torch.bfloat16
+B, T, d, h, V, nh = 32, 1024, 768, 2048, 50280, 12
+M = B * T
+NT = {'nt qkv fwd': (M, 3 * d, d), 'nt out fwd': (M, d, d), 'nt fc1 fwd': (M, 2 * h, d), 'nt fc2 fwd': (M, d, h), 'nt head fwd': (M, V, d),
+      'nt dX qkv': (M, d, 3 * d), 'nt dX fc1': (M, d, 2 * h), 'nt dX fc2': (M, h, d), 'nt dX head': (M, d, 50304)}
+TN = {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M), 'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}
+
+
+def main():
+  lib = _lib.load()
+  order = []
+
+  def entry(name, match, flops, alg, **shape):
+    order.append(dict(name=name, match=match, flops=flops, algorithmic_bytes=alg, **shape))
+
+  for name, (m, n, k) in NT.items():
+    A = torch.randn(m, k, device='cuda').to(BF)
+    Bm = torch.randn(n, k, device='cuda').to(BF)
+    out = torch.empty(m, n, device='cuda', dtype=BF)
+    torch.cuda.synchronize()
+    for _ in range(2):
+      ops.gemm_nt(A, Bm, out=out)
+    torch.cuda.synchronize()
+    entry(name, 'gemm_nt', 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n), M=m, N=n, K=k)
+    if lib.plm_gemm_nt_workspace_bytes(m, n, k) > 0:
+      entry(name + ' (stream-K reduce)', 'nt_streamk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
+    del A, Bm, out
+  for name, (m, n, k) in TN.items():
+    A = torch.randn(k, m, device='cuda').to(BF)
+    Bm = torch.randn(k, n, device='cuda').to(BF)
+    out = torch.zeros(m, n, device='cuda')
+    torch.cuda.synchronize()
+    for _ in range(2):
+      ops.gemm_tn(A, Bm, out=out, accumulate=True)
+    torch.cuda.synchronize()
+    entry(name, 'gemm_tn', 2.0 * m * n * k, 2.0 * (m * k + n * k) + 8.0 * m * n, M=m, N=n, K=k)
+    if lib.plm_gemm_tn_workspace_bytes(m, n, k) > 0:
+      entry(name + ' (split-K reduce)', 'splitk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
+    del A, Bm, out
+  # the four dW GEMMs of a block as the engine issues them: one grouped launch + one reduce
+  gp = []
+  for name in ('tn dW qkv', 'tn dW out', 'tn dW fc1', 'tn dW fc2'):
+    m, n, k = TN[name]
+    gp.append((torch.randn(k, m, device='cuda').to(BF), torch.randn(k, n, device='cuda').to(BF), torch.zeros(m, n, device='cuda'), False, None))
+  torch.cuda.synchronize()
+  for _ in range(2):
+    assert ops.gemm_tn_grouped(gp)
+  torch.cuda.synchronize()
+  fl = sum(2.0 * a.shape[1] * b.shape[1] * a.shape[0] for a, b, *_ in gp)
+  alg = sum(2.0 * (a.numel() + b.numel()) + 4.0 * o.numel() for a, b, o, *_ in gp)
+  entry('tn dW block (grouped x4)', 'gemm_tn', fl, alg, K=M)
+  entry('tn dW block (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of='tn dW block (grouped x4)')
+  del gp
+  # attention: the step's inputs have the statistics of a freshly initialised model (projection outputs ~N(0, 0.4))
+  qkv = (0.4 * torch.randn(M, 3 * d, device='cuda')).to(BF)
+  dout = (0.01 * torch.randn(M, d, device='cuda')).to(BF)
+  from plainlm_amd.transformer import rope_tables
+  cos, sin = (t_.cuda() for t_ in rope_tables(64, T))
+  torch.cuda.synchronize()
+  for _ in range(2):
+    out, lse = ops.attn_fwd(qkv, B, T, nh)
+  torch.cuda.synchronize()
+  att_fl = 4.0 * B * nh * 64 * T * (T + 1) / 2
+  entry('attn fwd', 'attn_fwd', att_fl, 2.0 * (M * 3 * d + M * d), B=B, T=T, nh=nh)
+  for _ in range(2):
+    ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh)
+  torch.cuda.synchronize()
+  for kname in ('attn_bwd_dq', 'attn_bwd_dkdv', 'attn_bwd_fused', 'attn_bwd_dq_reduce'):
+    order.append(dict(name=kname, match=kname, flops=2.0 * att_fl if kname in ('attn_bwd_fused',) else att_fl, algorithmic_bytes=2.0 * (M * 3 * d * 2 + M * d * 2),
+                      B=B, T=T, nh=nh, optional=True))
+  print('ORDER ' + json.dumps({'csrc_sha': csrc_sha(), 'launches': order}))
+
+
+if __name__ == '__main__':
+  main()
