@@ -248,8 +248,9 @@ def main():
   force_reducer = world == 1 and os.environ.get('PLM_FORCE_REDUCER')  # one-GPU what-if: the whole DDP data plane with a 1-rank communicator
   if world > 1 or force_reducer:
     comm = ddp.make_comm(device, a.comm)
+    comm_tail = ddp.make_tail_comm(comm)
     reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
-                              reserve_cus=ddp.COMM_CUS if force_reducer else None, writers=model.grad_writers())
+                              reserve_cus=ddp.COMM_CUS if force_reducer else None, writers=model.grad_writers(), comm_tail=comm_tail)
     reducer.broadcast_params([p.data for p in params])
     model.sink.on_ready = reducer.param_ready
 
@@ -328,7 +329,9 @@ def main():
   if reducer is not None:  # which data plane actually ran (make_comm may fall back from direct RCCL to torch's nccl backend)
     out['comm'] = {'backend': reducer.comm.backend, 'ranks': reducer.comm.world_size, 'buckets': len(reducer.buckets),
                    'bucket_cap_mb': a.bucket_mb, 'cu_reserve': reducer.reserve_cus,
-                   'nccl_max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS')}
+                   'max_ctas_overlapped_buckets': getattr(reducer.comm, 'max_ctas', None),
+                   'tail_communicator': 'uncapped split' if reducer.comm_tail is not None else 'none (tail bucket on the same communicator)',
+                   'nccl_max_nchannels_env': os.environ.get('NCCL_MAX_NCHANNELS')}
 
   if not a.no_extras:
     # ---- roofline leg: identical steps with HIP events around every MFMA kernel launch (untimed) ----
@@ -361,7 +364,7 @@ def main():
       opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
       if reducer is not None:
         reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
-                                  reserve_cus=reducer.reserve_cus, writers=model.grad_writers())
+                                  reserve_cus=reducer.reserve_cus, writers=model.grad_writers(), comm_tail=reducer.comm_tail)
         model.sink.on_ready = reducer.param_ready
 
       def full(i):

@@ -193,6 +193,14 @@ int plm_set_cu_reserve(int n);
 typedef struct plm_comm plm_comm_t;
 int plm_comm_unique_id(uint8_t uid[128]);
 int plm_comm_init(plm_comm_t** comm, const uint8_t uid[128], int rank, int world_size, int device);
+/* Same, with a per-communicator cap on the workgroups (= CUs) RCCL may use for one collective (ncclConfig_t.maxCTAs;
+ * max_ctas <= 0: RCCL's default).  Gradient buckets reduced WHILE backward is still running go through a capped
+ * communicator (the persistent GEMMs leave exactly that many CUs free, plm_set_cu_reserve), the buckets that become ready
+ * when backward has ended - embed_tokens, 154 MB, ready last: engine/engine.py:104-105 leaves it exposed too - go through
+ * an uncapped one obtained with plm_comm_split: with nothing left to overlap with, the tail should use every xGMI link. */
+int plm_comm_init_capped(plm_comm_t** comm, const uint8_t uid[128], int rank, int world_size, int device, int max_ctas);
+/* ncclCommSplit of `parent` into a communicator over the same ranks with its own CTA cap (collective over parent's ranks). */
+int plm_comm_split(plm_comm_t* parent, plm_comm_t** child, int max_ctas);
 int plm_comm_destroy(plm_comm_t* comm);
 /* in-place all-reduce-mean of a fp32 span on `stream` (the side stream owned by the caller) */
 int plm_comm_allreduce_avg_f32(plm_comm_t* comm, float* buf, int64_t count, void* stream);

@@ -74,6 +74,8 @@ SIGNATURES = {
   'plm_set_cu_reserve': (_I, [_I]),
   'plm_comm_unique_id': (_I, [_P]),
   'plm_comm_init': (_I, [C.POINTER(_P), _P, _I, _I, _I]),
+  'plm_comm_init_capped': (_I, [C.POINTER(_P), _P, _I, _I, _I, _I]),
+  'plm_comm_split': (_I, [_P, C.POINTER(_P), _I]),
   'plm_comm_destroy': (_I, [_P]),
   'plm_comm_allreduce_avg_f32': (_I, [_P, _P, _I64, _P]),
   'plm_comm_broadcast_f32': (_I, [_P, _P, _I64, _I, _P]),

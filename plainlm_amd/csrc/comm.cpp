@@ -35,7 +35,41 @@ extern "C" int plm_comm_unique_id(uint8_t uid[128]) {
   return PLM_OK;
 }
 
+static void capped_config(ncclConfig_t* cfg, int max_ctas) {
+  if (max_ctas > 0) {
+    cfg->minCTAs = 1;
+    cfg->maxCTAs = max_ctas;
+  }
+}
+
 extern "C" int plm_comm_init(plm_comm_t** out, const uint8_t uid[128], int rank, int world_size, int device) {
+  return plm_comm_init_capped(out, uid, rank, world_size, device, 0);
+}
+
+extern "C" int plm_comm_split(plm_comm_t* parent, plm_comm_t** child, int max_ctas) {
+  if (!parent || !child) {
+    plm_set_error("plm_comm_split: null pointer");
+    return PLM_E_INVALID;
+  }
+  hipError_t e = hipSetDevice(parent->device);
+  if (e != hipSuccess) {
+    plm_set_error("plm_comm_split: hipSetDevice(%d): %s", parent->device, hipGetErrorString(e));
+    return PLM_E_HIP;
+  }
+  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+  capped_config(&cfg, max_ctas);
+  plm_comm* c = new plm_comm{nullptr, parent->rank, parent->world, parent->device};
+  ncclResult_t r = ncclCommSplit(parent->comm, /*color*/ 0, /*key*/ parent->rank, &c->comm, &cfg);
+  if (r != ncclSuccess || c->comm == nullptr) {
+    plm_set_error("ncclCommSplit: %s", ncclGetErrorString(r));
+    delete c;
+    return PLM_E_COMM;
+  }
+  *child = c;
+  return PLM_OK;
+}
+
+extern "C" int plm_comm_init_capped(plm_comm_t** out, const uint8_t uid[128], int rank, int world_size, int device, int max_ctas) {
   if (!out || !uid || world_size < 1 || rank < 0 || rank >= world_size) {
     plm_set_error("plm_comm_init: bad arguments (rank=%d world=%d)", rank, world_size);
     return PLM_E_INVALID;
@@ -48,9 +82,11 @@ extern "C" int plm_comm_init(plm_comm_t** out, const uint8_t uid[128], int rank,
   ncclUniqueId id;
   memcpy(&id, uid, 128);
   plm_comm* c = new plm_comm{nullptr, rank, world_size, device};
-  ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
+  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+  capped_config(&cfg, max_ctas);
+  ncclResult_t r = max_ctas > 0 ? ncclCommInitRankConfig(&c->comm, world_size, id, rank, &cfg) : ncclCommInitRank(&c->comm, world_size, id, rank);
   if (r != ncclSuccess) {
-    plm_set_error("ncclCommInitRank: %s", ncclGetErrorString(r));
+    plm_set_error("ncclCommInitRank%s: %s", max_ctas > 0 ? "Config" : "", ncclGetErrorString(r));
     delete c;
     return PLM_E_COMM;
   }

@@ -27,11 +27,10 @@ from . import _lib
 # finish(), so the forward pass and the lm_head backward (no collective in flight) keep all 256 CUs (the reserve costs
 # 5.5 % on the GEMMs it applies to, run 30).
 COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
-if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-  # RCCL reads this when the FIRST communicator of the process is created - which may be torch.distributed's own
-  # (init_process_group('nccl') in a reference-style train.py) - so it is set when this module is imported, not only when
-  # our communicator is built.
-  os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
+# The cap is PER COMMUNICATOR (ncclConfig_t.maxCTAs through plm_comm_init_capped), not the process-wide NCCL_MAX_NCHANNELS:
+# the buckets that are reduced while backward runs use the capped communicator, the tail (embed_tokens: ready when backward
+# has ended, nothing left to overlap with) uses an uncapped one split off it, so the exposed 154 MB all-reduce runs on every
+# channel / xGMI link RCCL wants.  Only the torch.distributed fallback still needs the environment variable.
 
 
 class RcclComm:
@@ -42,10 +41,14 @@ class RcclComm:
   every rank together and make_comm's fallback stays in step.  A failure INSIDE ncclCommInitRank on a subset of the ranks is
   not recoverable (the others block in it) - that is RCCL's contract, not ours."""
 
-  def __init__(self, rank, world_size, device_index, store_group=None):
-    if world_size > 1:
-      os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
+  def __init__(self, rank, world_size, device_index, store_group=None, max_ctas=None, _handle=None):
     lib = _lib.load()
+    self.lib, self.rank, self.world_size, self.device_index = lib, rank, world_size, device_index
+    self.max_ctas = (COMM_CUS if world_size > 1 else 0) if max_ctas is None else int(max_ctas)
+    self.backend = 'rccl-direct'
+    if _handle is not None:  # split()
+      self.handle = _handle
+      return
     uid, err = (C.c_uint8 * 128)(), None
     if rank == 0:
       try:
@@ -62,10 +65,15 @@ class RcclComm:
     elif err is not None:
       raise err
     handle = C.c_void_p()
-    _lib.check(lib.plm_comm_init(C.byref(handle), C.cast(uid, C.c_void_p), rank, world_size, device_index), 'plm_comm_init')
-    self.handle, self.lib = handle, lib
-    self.rank, self.world_size = rank, world_size
-    self.backend = 'rccl-direct'
+    _lib.check(lib.plm_comm_init_capped(C.byref(handle), C.cast(uid, C.c_void_p), rank, world_size, device_index, self.max_ctas),
+               'plm_comm_init_capped')
+    self.handle = handle
+
+  def split(self, max_ctas=0):
+    """A second communicator over the same ranks with its own CTA cap (0 = RCCL's default); collective."""
+    child = C.c_void_p()
+    _lib.check(self.lib.plm_comm_split(self.handle, C.byref(child), int(max_ctas)), 'plm_comm_split')
+    return RcclComm(self.rank, self.world_size, self.device_index, max_ctas=max_ctas, _handle=child)
 
   def allreduce_avg_(self, span, stream):
     _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),
@@ -120,6 +128,12 @@ def plan_buckets(spans, cap_bytes):
     cur_bytes += nbytes
   if cur:
     buckets.append(cur)
+  # a trailing bucket of small tensors (< 1 MiB: the norm weights, which FlatAdamW lays in front of embed_tokens) joins its
+  # predecessor instead of costing one more latency-bound collective at the very end of backward
+  if len(buckets) >= 2:
+    last, prev = (sum(spans[i][1] for i in b) * 4 for b in (buckets[-1], buckets[-2]))
+    if last < (1 << 20) and last * 100 < prev:
+      buckets[-2].extend(buckets.pop())
   out = []
   for b in buckets:
     lo = min(spans[i][0] for i in b)
@@ -138,13 +152,17 @@ class GradReducer:
   """
 
   def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False, reserve_cus=None,
-               writers=None):
+               writers=None, comm_tail=None):
     """writers: optional {id(param): n} = how many backward kernels write that parameter's gradient per backward pass
     (default 1).  A weight shared by lm_head and embed_tokens (tie_embeddings, models/transformer.py:131-132) has two: the
     head's dW first, the embedding scatter last.  A bucket is launched only when every writer of every member has
     reported; launching after the first would let RCCL reduce the span in place while the second kernel still adds to it."""
     self.flat = flat_grad
     self.comm = comm
+    # Buckets that become ready when backward has ended (nothing left to hide them behind) go through comm_tail when one is
+    # given (see COMM_CUS): the bucket of params[0] - embed_tokens, whose gradient is the last kernel of backward - and
+    # whatever finish() still has to launch.
+    self.comm_tail = comm_tail
     self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)))
     self.index_of = {id(p): i for i, p in enumerate(params)}
     self.writers = [int((writers or {}).get(id(p), 1)) for p in params]
@@ -154,6 +172,7 @@ class GradReducer:
     for b, (_, _, idxs) in enumerate(self.buckets):
       for i in idxs:
         self.bucket_of[i] = b
+    self.tail_bucket = self.bucket_of[0] if params else -1
     self.on_gpu = flat_grad.is_cuda
     self.overlap = overlap and self.on_gpu
     self.stream = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
@@ -170,23 +189,25 @@ class GradReducer:
   def begin(self, sync):
     self.sync = bool(sync) and (self.comm.world_size > 1 or self.force)
     self.pending = [sum(self.writers[i] for i in idxs) for (_, _, idxs) in self.buckets]
+    self.reports = [0] * len(self.writers)
     self.launched = []
 
-  def _launch(self, b):
+  def _launch(self, b, tail=False):
     lo, hi, _ = self.buckets[b]
     span = self.flat[lo:hi]
+    comm = self.comm_tail if (self.comm_tail is not None and (tail or b == self.tail_bucket)) else self.comm
     if self.on_gpu:
       ev = torch.cuda.Event()
       ev.record(torch.cuda.current_stream())
       self.stream.wait_event(ev)
       with torch.cuda.stream(self.stream):
-        self.comm.allreduce_avg_(span, self.stream)
+        comm.allreduce_avg_(span, self.stream)
       if self.reserve_cus and not self._reserved:  # GEMMs enqueued from here on may run beside a collective
         from . import ops
         ops.set_cu_reserve(self.reserve_cus)
         self._reserved = True
     else:
-      self.comm.allreduce_avg_(span, None)
+      comm.allreduce_avg_(span, None)
     self.launched.append(b)
 
   def param_ready(self, p):
@@ -196,10 +217,11 @@ class GradReducer:
     if i is None:
       return
     b = self.bucket_of[i]
-    self.pending[b] -= 1
-    if self.pending[b] < 0:
+    self.reports[i] += 1
+    if self.reports[i] > self.writers[i]:
       raise RuntimeError(f'GradReducer: parameter {i} reported more gradient writes than declared ({self.writers[i]}); '
                          'a shared weight needs writers={id(p): n}')
+    self.pending[b] -= 1
     if self.pending[b] == 0 and self.overlap:
       self._launch(b)
 
@@ -209,7 +231,7 @@ class GradReducer:
       return
     for b in range(len(self.buckets)):
       if b not in self.launched:
-        self._launch(b)
+        self._launch(b, tail=True)
     if self.on_gpu:
       torch.cuda.current_stream().wait_stream(self.stream)
     if self._reserved:  # everything enqueued after the join runs with no collective in flight
@@ -255,11 +277,30 @@ def make_comm(device, backend=None, group=None):
     if comm is not None:
       comm.close()
     print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl', flush=True)
-    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))  # process-wide cap: the only knob torch's backend offers
     return TorchDistComm(dist.new_group(backend='nccl'))
   if not dist.is_initialized():
     raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")
   return TorchDistComm(group)
+
+
+def make_tail_comm(comm, group=None):
+  """Uncapped communicator for the buckets that are reduced after backward has ended (see COMM_CUS), split off the capped
+  one; None when the data plane is not direct RCCL, the capped one is not capped, PLM_COMM_TAIL=0, or the split fails on
+  any rank (every rank then keeps using `comm` alone - agreed collectively)."""
+  if not isinstance(comm, RcclComm) or comm.max_ctas <= 0 or os.environ.get('PLM_COMM_TAIL', '1') == '0':
+    return None
+  tail, err = None, None
+  try:
+    tail = comm.split(max_ctas=0)
+  except RuntimeError as e:
+    err = e
+  if all_ranks_ok(err is None, group):
+    return tail
+  if tail is not None:
+    tail.close()
+  print(f'[plainlm_amd.ddp] rank {comm.rank}: no uncapped tail communicator ({err}); the tail bucket uses the capped one', flush=True)
+  return None
 
 
 def all_ranks_ok(ok, group=None):

@@ -201,7 +201,7 @@ class HipEngine(torch.nn.Module):
     if dist.is_initialized() and dist.get_world_size() > 1:
       comm = ddp.make_comm(device, comm_backend)
       self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb,
-                                      writers=self.model.grad_writers())
+                                      writers=self.model.grad_writers(), comm_tail=ddp.make_tail_comm(comm))
       self.reducer.broadcast_params([p.data for p in self.params])  # DDP ctor's _sync_module_states
       self.model.invalidate_shadows()
       self.model.sink.on_ready = self.reducer.param_ready

@@ -36,11 +36,18 @@ class FlatAdamW(torch.optim.AdamW):
     self.flat_g = model._flat_grad
     if self.flat_g.numel() != total:
       raise ValueError('flat gradient buffer does not match the parameter groups')
-    self.group_spans = []
+    self.group_spans = [None] * len(self.param_groups)
     self._views = {}
     off = 0
     spans_by_param = {}
-    for g in self.param_groups:
+    # Placement: zero-weight-decay groups (the norm weights, 77 KB at 160M) FIRST, so that the flat buffer reads
+    # [norms | embed_tokens | layer 0 ... | lm_head]: ddp.plan_buckets walks it from the end (= the order gradients become
+    # ready) and the norm weights - complete only when layer 0 has been differentiated - share the LAST bucket with
+    # embed_tokens instead of holding up lm_head's.  param_groups keeps the reference's order (decay, no-decay): only the
+    # placement changes, optimizer.state_dict() does not.
+    placement = sorted(range(len(self.param_groups)), key=lambda i: (self.param_groups[i]['weight_decay'] != 0.0, i))
+    for gi in placement:
+      g = self.param_groups[gi]
       lo = off
       for p in g['params']:
         n = p.numel()
@@ -50,7 +57,7 @@ class FlatAdamW(torch.optim.AdamW):
         spans_by_param[id(p)] = (off, n)
         self._views[id(p)] = (self.flat_m[off:off + n].view(p.shape), self.flat_v[off:off + n].view(p.shape))
         off += n
-      self.group_spans.append((lo, off))
+      self.group_spans[gi] = (lo, off)
     # the model's span table (used by the gradient reducer) follows parameters() order
     model._grad_spans = [spans_by_param[id(p)] for p in model.parameters()]
     model.invalidate_shadows()

@@ -178,3 +178,23 @@ def test_bench_metric_definition():
     assert 'traffic_note' in tr
   assert bench.pmc_traffic('gemm_nt', '420m', 16384, 24) == {}
   assert len(bench.csrc_sha()) == 16 and bench.physical_cores() >= 1
+
+
+def test_bucket_plan_160m_engine_layout():
+  """FlatAdamW's placement at the 160M size: [25 norm weights | embed_tokens | 12 x (w_qkv, w_out, fc1, fc2) | lm_head].
+  Walking it from the end (the order gradients become ready): lm_head alone goes first, the layers follow in <= 64 MiB
+  buckets, and the LAST collective carries embed_tokens together with the 77 KB of norm weights (complete only when
+  layer 0 has been differentiated) - one tail collective, not two; every bucket is one contiguous span."""
+  d, h, V, L = 768, 2048, 50280, 12
+  sizes = [d] * (2 * L + 1) + [V * d] + [3 * d * d, d * d, 2 * h * d, d * h] * L + [V * d]
+  spans, off = [], 0
+  for n in sizes:
+    spans.append((off, n))
+    off += n
+  assert off == 162_183_936  # SURVEY A12 [probed]
+  b = ddp.plan_buckets(spans, cap_bytes=64 << 20)
+  n_norm = 2 * L + 1
+  assert b[0][2] == [len(sizes) - 1]                               # lm_head: first to be reduced, alone
+  assert b[-1][2] == list(range(n_norm + 1))                       # norms + embed_tokens: the tail
+  assert all((hi - lo) * 4 <= (64 << 20) for lo, hi, _ in b[1:-1])
+  assert sum(hi - lo for lo, hi, _ in b) == off and len(b) <= 12
