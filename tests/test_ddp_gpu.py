@@ -55,6 +55,10 @@ def _worker(rank, world, port, out_dir, tied, bucket_mb):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
   dist.init_process_group('gloo', rank=rank, world_size=world)
   torch.cuda.set_device(0)
+  # no CUs set aside for the collectives here: the persistent GEMMs then make the same tile / split-K plans as the
+  # single-process run this test compares with (a different plan = a different fp32 summation order = occasional bf16
+  # rounding flips downstream; the reserve itself is covered by test_gemms_with_cu_reserve / test_rccl_reducer_single_rank)
+  os.environ['PLM_COMM_CUS'] = '0'
   import plainlm_amd as P
   from plainlm_amd import ddp
   cfg = _cfg(2, tied)

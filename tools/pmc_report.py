@@ -7,7 +7,7 @@ each ORDER entry the next two dispatches whose kernel name contains its `match` 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950
 FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads, so it is doubled; both are L2-miss side
 (Infinity-Cache hits included).  SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16, summed over the chip:
-MFMA utilisation = busy / (GRBM_GUI_ACTIVE * 1024 SIMDs); the expected busy count from the algorithmic flops is printed
+MFMA utilisation = busy / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) (the counter is summed over the XCDs: GRBM / 8 / duration gives the ~2 GHz clock); the expected busy count from the algorithmic flops is printed
 beside it as a calibration of that reading (ratio > 1: recomputed work, e.g. the two-pass attention backward)."""
 import csv
 import glob
@@ -42,11 +42,16 @@ def main(order_log, out_json, *dirs):
         if e['match'] in disp[p]['name'] and not (e['match'].startswith('gemm_') and 'reduce' in disp[p]['name']):
           found.append(p)
         p += 1
-      if len(found) < 2:
-        if not e.get('optional'):
-          raise SystemExit(f'{d}: launch {e["name"]} not found after dispatch {pos}')
-        got.append(None)
+      if 'part_of' in e:  # a reduce kernel that follows each launch of its GEMM: the (warm) one right behind the kept dispatch
+        prev = next((q for q in range(pos - 1, len(disp)) if e['match'] in disp[q]['name']), None)
+        got.append(disp[prev] if prev is not None else None)
         continue
+      if e.get('optional'):  # kernels of one multi-kernel op (attention backward): interleaved dispatches, keep the last (warm) one
+        allm = [q for q in range(pos, len(disp)) if e['match'] in disp[q]['name']]
+        got.append(disp[allm[-1]] if allm else None)
+        continue
+      if len(found) < 2:
+        raise SystemExit(f'{d}: launch {e["name"]} not found after dispatch {pos}')
       pos = found[1] + 1
       got.append(disp[found[1]])
     per_pass.append(got)
@@ -65,7 +70,7 @@ def main(order_log, out_json, *dirs):
       row['write_bytes'] = 1024.0 * c['WRITE_SIZE']
       row['traffic_bytes'] = row['fetch_bytes'] + row['write_bytes']
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and c.get('GRBM_GUI_ACTIVE'):
-      row['mfma_util'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024.0), 4)
+      row['mfma_util'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4)  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
       if e['flops']:
         row['mfma_busy_over_algorithmic'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (32.0 * e['flops'] / (2 * 32 * 32 * 16)), 3)
     res['rows'].append(row)
