@@ -365,7 +365,7 @@ def _random_docs(B, T, seed):
   return out
 
 
-@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (1, 128, 1), (2, 256, 3), (1, 1024, 2), (1, 200, 2), (1, 2048, 1)])
+@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (1, 128, 1), (2, 256, 3), (1, 1024, 2), (1, 200, 2), (1, 2048, 1), (2, 320, 2), (3, 512, 1), (1, 836, 2)])
 @pytest.mark.parametrize('masked', [False, True])
 def test_attention_fwd_bwd(ops, B, T, nh, masked):
   g = torch.Generator().manual_seed(T * nh + masked)
