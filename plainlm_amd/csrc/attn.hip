@@ -522,7 +522,9 @@ __device__ __forceinline__ void pp_barrier() {  // slot boundary: everything of 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool HAS_DOC>
+// ABL (timing-only builds, PLM_ATTN_ABL=<n>, results are WRONG for n >= 2): 1 = wait for every wave's LDS-DMA in each V slot
+// (the first version of the schedule), 2 = no softmax arithmetic, 3 = no MFMAs, 4 = no transposed LDS reads, 5 = no barriers.
+template <bool HAS_DOC, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv8_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 const float* __restrict__ rcos, const float* __restrict__ rsin,
@@ -662,13 +664,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv8_kernel(const uint16_t* 
   if (ntile > 1) stage_tile(1);
   attn_wait_vm<0>();
   pp_barrier();
-  if (grp == 1) pp_barrier();
+  if (grp == 1 && ABL != 5) pp_barrier();
   bool act_prev = false;  // block bi-1 produced P / dS (its dV / dK MFMAs are due)
   for (int bi = 0; bi <= nb; ++bi) {
     // ================= M slot: matrix pipe (the 8 row-fragment reads of S / dP land under the dV / dK MFMAs) =================
     const bool act = blk_active(bi);
     if (act) read_rows(bi);
-    if (act_prev) {
+    if (act_prev && ABL != 3) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -680,26 +682,37 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv8_kernel(const uint16_t* 
     if (act) {
       zero16(s);
       zero16(dp);
+      if (ABL != 3) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(rq[ks], kf[ks], s);       // S[q][kv]
-        dp = mfma32(rdo[ks], vf[ks], dp);    // dP[q][kv]
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma32(rq[ks], kf[ks], s);       // S[q][kv]
+          dp = mfma32(rdo[ks], vf[ks], dp);    // dP[q][kv]
+        }
+      } else {
+        asm volatile("" ::"v"(rq[0]), "v"(rq[1]), "v"(rq[2]), "v"(rq[3]), "v"(rdo[0]), "v"(rdo[1]), "v"(rdo[2]), "v"(rdo[3]));
       }
     }
-    pp_barrier();
+    if (ABL != 5) pp_barrier();
     // ================= V slot: vector + LDS + DMA =================
-    attn_wait_vm<0>();  // this wave's LDS-DMA of the previous V slot (two intervals ago) has landed
+    // A tile is staged 4 intervals before the first wave reads it and every wave waits for ITS pieces just before it issues
+    // the next tile's (one V slot in two): by then the DMA has had 4 intervals to land, and the barrier that follows the
+    // wait publishes it at least one interval before the first read.
+    if (ABL == 1 || !(bi & 1)) attn_wait_vm<0>();
     if (!(bi & 1) && (bi >> 1) + 2 < ntile) stage_tile((bi >> 1) + 2);  // its ring slot was last read two intervals ago
     if (act) {
-      read_tr(bi);
+      if (ABL != 4) read_tr(bi);
       const int q0 = blk_q0(bi);
       const bool need_mask = HAS_DOC || q0 < kvw0 + 31 || q0 + 32 > T;
-      if (need_mask) softmax(bi, std::true_type{}); else softmax(bi, std::false_type{});
+      if (ABL == 2) {
+        asm volatile("" ::"v"(s), "v"(dp));
+      } else {
+        if (need_mask) softmax(bi, std::true_type{}); else softmax(bi, std::false_type{});
+      }
     }
     act_prev = act;
-    pp_barrier();
+    if (ABL != 5) pp_barrier();
   }
-  if (grp == 0) pp_barrier();  // balances group 1's extra barrier
+  if (grp == 0 && ABL != 5) pp_barrier();  // balances group 1's extra barrier
   attn_wait_vm<0>();
 
   if (kvalid) {
@@ -934,7 +947,12 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
     if (v1) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    else hipLaunchKernelGGL(attn_bwd_dkdv8_kernel<false>, gkv8, block8, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    else {
+      static const int abl = getenv("PLM_ATTN_ABL") ? atoi(getenv("PLM_ATTN_ABL")) : 0;
+#define PLM_DKDV8(A) hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<false, A>), gkv8, block8, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh)
+      if (abl == 1) PLM_DKDV8(1); else if (abl == 2) PLM_DKDV8(2); else if (abl == 3) PLM_DKDV8(3); else if (abl == 4) PLM_DKDV8(4); else if (abl == 5) PLM_DKDV8(5); else PLM_DKDV8(0);
+#undef PLM_DKDV8
+    }
   }
   PLM_CHECK_LAUNCH("plm_attn_bwd");
   return PLM_OK;
