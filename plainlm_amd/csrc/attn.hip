@@ -21,98 +21,7 @@
 
 #include <type_traits>
 
-#define HD 64
-#define LOG2E 1.4426950408889634f
-
-// raw v_exp_f32: arguments here are <= 0 (or -inf), so no denormal-range fix-up is needed
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// interleaved-pair rotation of 8 consecutive head dims (4 pairs); sgn = +1 forward, -1 inverse (gradient)
-__device__ __forceinline__ bf16x8_t rope8(bf16x8_t v, f32x4_t c, f32x4_t s, float sgn) {
-  bf16x8_t o;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float a = bf2f(v[2 * p]), b = bf2f(v[2 * p + 1]);
-    const float sn = s[p] * sgn;
-    o[2 * p] = f2bf(a * c[p] - b * sn);
-    o[2 * p + 1] = f2bf(b * c[p] + a * sn);
-  }
-  return o;
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS image of a [rows][64 d] bf16 tile: row-major, 128-byte rows (so one LDS-DMA wave-instruction =
-// 8 whole rows = 8 fully used 128-byte global segments).  Inside row r (bits b0..b3) the logical 16-byte
-// chunk c = 2*pair + half is stored at pair' = (pair + 2*b1 + b3) & 3, half' = half ^ b2:
-//   * ds_read_b128 of one chunk across 16 rows (r mod 16 distinct) hits 16 different 16-byte slots of
-//     the 256-byte bank row (b0 picks the 128-byte half, (b1,b3) the pair, b2 the half): conflict-free;
-//   * ds_read_b64_tr_b16 of a [4 rows][16 cols] block (rows R..R+3, R % 4 == 0) puts the four rows on
-//     four different 32-byte segments, and the neighbouring 16-column block on the other four.
-// The permutation is applied on the DMA SOURCE address (the DMA itself writes lane-linear).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int rs_off(int row, int c) {
-  const int pp = ((c >> 1) + 2 * ((row >> 1) & 1) + ((row >> 3) & 1)) & 3;
-  const int ph = (c & 1) ^ ((row >> 2) & 1);
-  return row * 128 + pp * 32 + ph * 16;
-}
-__device__ __forceinline__ int rs_logical_chunk(int row, int pc) {  // inverse: physical chunk pc of row -> logical chunk
-  const int cb = ((pc >> 1) - 2 * ((row >> 1) & 1) - ((row >> 3) & 1)) & 3;
-  return cb * 2 + ((pc & 1) ^ ((row >> 2) & 1));
-}
-
-// A-operand fragment (rows i = tile rows, k = head dims ks*16 + hi*8 ..) by ds_read_b128
-__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row, int ks, int hi) {
-  return *reinterpret_cast<const bf16x8_t*>(tile + rs_off(row, ks * 2 + hi));
-}
-// A-operand fragment (rows i = head dims db*32 + (lane&31), k = tile rows) by two transpose reads.
-// k-slot e of lane-half hi maps to tile row  rbase + (e&3) + 8*(e>>2)  — the row order in which a lane
-// holds the matching B operand after a transposed-score MFMA (see mfma32_row()).
-__device__ __forceinline__ bf16x8_t frag_cols(const char* tile, int db, int rbase, int lane) {
-  const int ib = (lane >> 4) & 1, t16 = lane & 15;
-  const int sub = t16 & 3;                 // 8-byte piece of the 32-byte (16-column) block
-  const int c = (db * 2 + ib) * 2 + (sub >> 1);
-  const int row = rbase + (t16 >> 2);
-  const char* p0 = tile + rs_off(row, c) + (sub & 1) * 8;
-  const char* p1 = tile + rs_off(row + 8, c) + (sub & 1) * 8;
-  return join_tr(lds_read_tr16(p0), lds_read_tr16(p1));
-}
-
-// LDS-DMA of a [64 rows][64 d] tile (8 KiB = 8 wave-instructions, two per wave).  `src` points at (row 0, d 0) of
-// the tile in global memory, `ld` is the row stride in elements; rows above `last_row` are clamped (their values are
-// masked out by the caller).
-struct TileDma {
-  int row[2], coff[2];
-  unsigned boff[2];  // byte offset of this lane's 16 bytes inside a full tile, for the row stride given to init()
-  __device__ __forceinline__ void init(int wave, int lane, int64_t ld = 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      row[i] = (i * 4 + wave) * 8 + (lane >> 3);
-      coff[i] = rs_logical_chunk(row[i], lane & 7) * 8;
-      boff[i] = (unsigned)((row[i] * ld + coff[i]) * 2);
-    }
-  }
-  __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave) const {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      dma16_asm(src + (int64_t)min(row[i], last_row) * ld + coff[i], dst_tile + (i * 4 + wave) * 1024);
-  }
-  // full tile (no row clamp), row stride = the one given to init(): wave-uniform base in SGPRs + constant lane offsets
-  __device__ __forceinline__ void issue_full(char* dst_tile, const uint16_t* src, int wave) const {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dma16_saddr_asm(src, boff[i], dst_tile + (i * 4 + wave) * 1024);
-  }
-};
-
-template <int N>
-__device__ __forceinline__ void attn_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void attn_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ void zero16(f32x16_t& v) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = 0.f;
-}
+#include "attn_common.h"
 
 // =============================================================================================
 // RoPE on the q and k column blocks of the w_qkv output, in place (models/embeddings.py:15-30):
@@ -895,6 +804,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 // =============================================================================================
 // C ABI
 // =============================================================================================
+void plm_launch_attn_bwd_dkdv_pipe(const uint16_t* qkv, const uint16_t* dout, const float* lse, const float* delta, const float* rope_cos,
+                                   const float* rope_sin, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);  // attn_pipe.hip
+
 static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, int64_t hd) {
   PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
   PLM_REQUIRE(B > 0 && T > 0 && nh > 0 && B < 65536 && nh < 65536 && T < (1 << 24), "%s: bad shape B=%ld T=%ld nh=%ld", name, (long)B,
@@ -942,11 +854,13 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   static const bool v1 = getenv("PLM_ATTN_BWD_V1") != nullptr;  // A/B: the 4-wave dK/dV kernel
   if (doc_start) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    if (v1) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    else hipLaunchKernelGGL(attn_bwd_dkdv8_kernel<true>, gkv8, block8, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    static const bool v8 = getenv("PLM_ATTN_DKDV8") != nullptr;  // A/B: the 8-wave ping-pong kernel
     if (v1) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    else if (!v8 && T % 128 == 0) plm_launch_attn_bwd_dkdv_pipe(qkv, dout, lse, delta, rope_cos, rope_sin, dqkv, B, T, nh, s);
+    else if (!v8) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
     else {
       static const int abl = getenv("PLM_ATTN_ABL") ? atoi(getenv("PLM_ATTN_ABL")) : 0;
 #define PLM_DKDV8(A) hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<false, A>), gkv8, block8, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh)

@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum Role { IDLE = 0, MFMA = 1, VFMA = 2, VEXP = 3, VCVT = 4, LDS = 5, MIX4 = 6, MIX6 = 7, MIX8 = 8, MIX8E = 9 };
+enum Role { IDLE = 0, MFMA = 1, VFMA = 2, VEXP = 3, VCVT = 4, LDS = 5, MIX4 = 6, MIX6 = 7, MIX8 = 8, MIX8E = 9, MFMA8 = 10, MFMA16S = 11, MFMA1 = 12, MFMA2 = 13, MFMA_A = 14 };
 
 template <int F, bool EXPS>
 __device__ __forceinline__ void mix_round(f32x16 (&acc)[4], bf16x8 a, bf16x8 b, float (&v)[16]) {
@@ -32,11 +32,15 @@ __device__ __forceinline__ void mix_round(f32x16 (&acc)[4], bf16x8 a, bf16x8 b, 
   }
 }
 
-__global__ __launch_bounds__(512, 2) void k(int role0, int role1, int iters, long long* cycles, float* sink) {
+template <int role0, int role1>
+__global__ __launch_bounds__(512, 2) void k(int iters, long long* cycles, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int role = wave < 4 ? role0 : role1;
+  constexpr bool U4 = role0 == MFMA || role1 == MFMA || role0 == MFMA1 || role1 == MFMA1 || role0 == MFMA2 || role1 == MFMA2 || role0 >= MIX4 && role0 <= MIX8E || role1 >= MIX4 && role1 <= MIX8E || role0 == MFMA8 || role1 == MFMA8 || role0 == MFMA_A || role1 == MFMA_A;
+  constexpr bool U8 = role0 == MFMA8 || role1 == MFMA8;
+  constexpr bool U16 = role0 == MFMA16S || role1 == MFMA16S;
   for (int i = threadIdx.x; i < 16384; i += 512) reinterpret_cast<float*>(smem)[i] = (float)i;
   __syncthreads();
   if (role == IDLE) return;
@@ -47,22 +51,47 @@ __global__ __launch_bounds__(512, 2) void k(int role0, int role1, int iters, lon
   for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (lane + e)); b[e] = (__bf16)(0.002f * (lane - e)); }
   float v[16];
   for (int j = 0; j < 16; ++j) v[j] = 0.01f * (lane + j);
+  f32x16 acc8[4];  // four more accumulators for the 8-chain role
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  f32x4v accs[16];  // 16x16x32: sixteen 4-register accumulators
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc8[i][r] = 0.f;
+  for (int i = 0; i < 16; ++i)
+    for (int r = 0; r < 4; ++r) accs[i][r] = 0.f;
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
-    if (role == MFMA) {
+    if ((role0 == MFMA8 || role1 == MFMA8) && role == MFMA8) {  // 16 MFMAs on 8 independent accumulators
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i & 4) acc8[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc8[i & 3], 0, 0, 0);
+        else acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+      }
+    } else if ((role0 == MFMA_A || role1 == MFMA_A) && role == MFMA_A) {  // 4 accumulators held in AGPRs (inline asm: hipcc prefers VGPRs)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i & 3]) : "v"(a), "v"(b));
+    } else if ((role0 == MFMA1 || role1 == MFMA1) && role == MFMA1) {  // 16 MFMAs on ONE accumulator (dependent chain)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0], 0, 0, 0);
+    } else if ((role0 == MFMA2 || role1 == MFMA2) && role == MFMA2) {  // two chains
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 1], 0, 0, 0);
+    } else if ((role0 == MFMA16S || role1 == MFMA16S) && role == MFMA16S) {  // 32 x v_mfma_f32_16x16x32_bf16 (same flops as 16 x 32x32x16) on 16 accumulators
+#pragma unroll
+      for (int i = 0; i < 32; ++i) accs[i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, accs[i & 15], 0, 0, 0);
+    } else if ((role0 == MFMA || role1 == MFMA) && role == MFMA) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
-    } else if (role == VFMA) {
+    } else if ((role0 == VFMA || role1 == VFMA) && role == VFMA) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_fmaf(v[j], 1.0001f, 0.5f);
-    } else if (role == VEXP) {
+    } else if ((role0 == VEXP || role1 == VEXP) && role == VEXP) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_exp2f(v[j]);
-    } else if (role == VCVT) {
+    } else if ((role0 == VCVT || role1 == VCVT) && role == VCVT) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -74,60 +103,74 @@ __global__ __launch_bounds__(512, 2) void k(int role0, int role1, int iters, lon
           v[j] = __builtin_fmaf((float)p[0], 1.0001f, 0.5f);
           v[j + 1] = __builtin_fmaf((float)p[1], 1.0001f, 0.25f);
         }
-    } else if (role == LDS) {
+    } else if ((role0 == LDS || role1 == LDS) && role == LDS) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + j * 1024 + it * 64) & 65535));
         v[j] = __builtin_fmaf(v[j], 1.0001f, q[0] + q[3]);
       }
-    } else if (role == MIX4) {
+    } else if ((role0 == MIX4 || role1 == MIX4) && role == MIX4) {
       mix_round<4, false>(acc, a, b, v);
-    } else if (role == MIX6) {
+    } else if ((role0 == MIX6 || role1 == MIX6) && role == MIX6) {
       mix_round<6, false>(acc, a, b, v);
-    } else if (role == MIX8) {
+    } else if ((role0 == MIX8 || role1 == MIX8) && role == MIX8) {
       mix_round<8, false>(acc, a, b, v);
-    } else if (role == MIX8E) {
+    } else if ((role0 == MIX8E || role1 == MIX8E) && role == MIX8E) {
       mix_round<8, true>(acc, a, b, v);
     }
   }
   const long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
-  for (int i = 0; i < 4; ++i)
-    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (U4)
+    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) s += acc[i][r];
   for (int j = 0; j < 16; ++j) s += v[j];
+  if (U8)
+    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) s += acc8[i][r];
+  if (U16)
+    for (int i = 0; i < 16; ++i)
+      for (int r = 0; r < 4; ++r) s += accs[i][r];
   if (s == 12345.678f) sink[0] = s;
   if (lane == 0 && blockIdx.x == 0) cycles[wave] = t1 - t0;
+}
+
+template <int R0, int R1>
+void run(const char* n0, const char* n1, long long* cyc, float* sink, hipEvent_t e0, hipEvent_t e1) {
+  const int iters = 2000;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k<R0, R1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipMemset(cyc, 0, 8 * sizeof(long long));
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<R0, R1>), dim3(256), dim3(512), 100 * 1024, 0, iters, cyc, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    long long h[8];
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    if (rep) printf("waves0-3=%-4s waves4-7=%-4s  cycles/round: w0 %7.1f  w4 %7.1f   wall %.3f ms\n", n0, n1, (double)h[0] / iters, (double)h[4] / iters, ms);
+  }
 }
 
 int main() {
   long long* cyc;
   float* sink;
-  hipMalloc(&cyc, 8 * sizeof(long long));
-  hipMalloc(&sink, 4);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-  const char* names[] = {"-", "M", "V", "E", "C", "L", "X4", "X6", "X8", "X8e"};
-  const int cfgs[][2] = {{MFMA, IDLE}, {IDLE, MFMA}, {MFMA, MFMA}, {VFMA, IDLE}, {VFMA, VFMA}, {MFMA, VFMA}, {VEXP, IDLE}, {VEXP, VEXP},
-                         {MFMA, VEXP}, {VCVT, IDLE}, {MFMA, VCVT}, {LDS, IDLE}, {LDS, LDS}, {MFMA, LDS}, {MIX4, IDLE}, {MIX6, IDLE},
-                         {MIX8, IDLE}, {MIX8E, IDLE}, {MIX4, MIX4}, {MIX8, MIX8}, {MIX8E, MIX8E}, {VFMA, VEXP}, {VFMA, LDS}};
-  const int iters = 2000;
+  (void)hipMalloc(&cyc, 8 * sizeof(long long));
+  (void)hipMalloc(&sink, 4);
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
-  printf("# cycles per round (s_memtime, wave 0 / wave 4 of workgroup 0); wall = chip-wide ms for %d rounds on 256 workgroups\n", iters);
-  for (auto& c : cfgs) {
-    for (int rep = 0; rep < 2; ++rep) {
-      hipMemset(cyc, 0, 8 * sizeof(long long));
-      hipEventRecord(e0);
-      hipLaunchKernelGGL(k, dim3(256), dim3(512), 100 * 1024, 0, c[0], c[1], iters, cyc, sink);
-      hipEventRecord(e1);
-      hipEventSynchronize(e1);
-      float ms;
-      hipEventElapsedTime(&ms, e0, e1);
-      long long h[8];
-      hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
-      if (rep) printf("waves0-3=%-3s waves4-7=%-3s  cycles/round: w0 %7.1f  w4 %7.1f   wall %.3f ms\n", names[c[0]], names[c[1]], (double)h[0] / iters,
-                      (double)h[4] / iters, ms);
-    }
-  }
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  printf("# cycles per round (s_memtime, wave 0 / wave 4 of workgroup 0); a round = 16 MFMA 32x32x16 (or 32 MFMA 16x16x32) = 512 cycles of matrix pipe at peak;\n# wall = chip-wide ms for 2000 rounds on 256 workgroups\n");
+#define RUN(A, B) run<A, B>(#A, #B, cyc, sink, e0, e1)
+  RUN(MFMA1, IDLE); RUN(MFMA2, IDLE); RUN(MFMA, IDLE); RUN(MFMA8, IDLE); RUN(MFMA16S, IDLE);
+  RUN(MFMA_A, IDLE); RUN(MFMA_A, MFMA_A); RUN(MFMA_A, VFMA);
+  RUN(MFMA1, MFMA1); RUN(MFMA2, MFMA2); RUN(MFMA, MFMA); RUN(MFMA8, MFMA8); RUN(MFMA16S, MFMA16S);
+  RUN(VFMA, IDLE); RUN(VFMA, VFMA); RUN(MFMA, VFMA); RUN(MFMA8, VFMA);
+  RUN(VEXP, IDLE); RUN(VEXP, VEXP); RUN(MFMA, VEXP);
+  RUN(VCVT, IDLE); RUN(MFMA, VCVT);
+  RUN(LDS, IDLE); RUN(LDS, LDS); RUN(MFMA, LDS);
+  RUN(MIX4, IDLE); RUN(MIX6, IDLE); RUN(MIX8, IDLE); RUN(MIX8E, IDLE); RUN(MIX4, MIX4); RUN(MIX8, MIX8); RUN(MIX8E, MIX8E);
+  RUN(VFMA, VEXP); RUN(VFMA, LDS);
   return 0;
 }
