@@ -98,13 +98,10 @@ int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
                      int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream);
 /* same as plm_gemm_bf16_nt with an explicit kernel choice (autotuning / A-B measurements / tests):
  * variant 0 = automatic, 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA double-buffered,
- * 3 = persistent 256x256 4-phase, 4 = persistent 256x128 4-phase, 5 / 6 = 3 / 4 with the two wave groups
- * staggered by one barrier, 7 / 8 = 3 / 4 with one barrier per K-tile, 9 = 256x256 with one wave per SIMD,
- * 10 / 11 = 3 / 4 with the deep-prefetch ring (half-tile slots refilled two K-tiles ahead),
- * 12 = persistent 256x192 (64x96 per wave) with the deep-prefetch ring,
- * 13 / 14 / 15 = 10 / 12 / 11 as a two-phase ring (two barriers per K-tile; faster back-to-back, slower in the step),
- * 16 / 17 / 18 = 10 / 12 / 11 with offset wave groups (the automatic choice)
- * (3..18: bf16 C, no accumulate; 2..18: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
+ * 3 = persistent 256x256, plain 4-phase LDS-DMA ring,
+ * 4 / 5 / 6 = persistent 256x256 / 256x192 / 256x128 with the deep-prefetch ring (half-tile slots refilled two K-tiles
+ *             ahead) and offset wave groups - the kernels the automatic policy chooses from
+ * (3..6: bf16 C, no accumulate; 2..6: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
 int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                         void* stream);
@@ -147,8 +144,8 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  *               kernel and read by the dK/dV kernel that follows it). */
 int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                 void* stream);
-/* w_qkv projection fused with RoPE (transformer.py:42-47): QKV[M, 3*nh*hd] = X[M,K] W[3*nh*hd, K]^T with the q | k
- * blocks rotated in the GEMM epilogue (falls back to GEMM + plm_rope_qk for shapes the big-tile kernel declines). */
+/* w_qkv projection + RoPE (transformer.py:42-47): QKV[M, 3*nh*hd] = X[M,K] W[3*nh*hd, K]^T, then the q | k blocks are
+ * rotated in place by plm_rope_qk (one HBM pass; ldq must be 3*nh*hd). */
 int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* QKV, int64_t ldq, int64_t M,
                       int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                       void* stream);

@@ -17,8 +17,6 @@
 // inverse rotation to dQ / dK in their epilogues, so dqkv is the gradient w.r.t. the PRE-rotation projection.
 #include "plm_device.h"
 
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "attn_common.h"
@@ -220,6 +218,16 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
 
 // =============================================================================================
 // backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows; q, k rotated)
+//
+// Why the backward stays two passes of 4-wave workgroups (round 2, profiles/r02_ubench_overlap.txt, r02_pmc_sq.txt):
+// the kernels are bound by instruction issue and LDS reads, not by the matrix pipe (27 % busy) - per 32x32 block a wave
+// issues 16 MFMAs next to ~100 VALU + 16 exp2 + 16 cvt + 28-32 LDS reads, and on this chip a ds_read_b128 costs its wave
+// 24-33 cycles of issue, a wave doing VALU / LDS work beside an MFMA-streaming partner on the same SIMD slows down 2.5-4x.
+// Measured against this kernel (177 us / layer at the 160M shape): an 8-wave form that alternates matrix and vector slots
+// between the two waves of a SIMD 268 us; a one-wave-per-SIMD three-stage software pipeline (MFMAs of blocks b-1 / b+1
+// interleaved with the softmax of block b) 269-285 us - with one wave per SIMD the LDS reads alone take ~1200 cycles per
+// block.  A single-pass kernel (dQ with dK / dV from one recomputation) saves 8 of 28 MFMAs per block but has to move
+// ~0.44 GB of fp32 dQ partials per layer through HBM twice to stay deterministic - no gain while the MFMAs are not the limit.
 // =============================================================================================
 template <bool HAS_DOC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
@@ -394,263 +402,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 }
 
 // =============================================================================================
-// backward: dK, dV, 8-wave ping-pong form  (one workgroup per 256 key rows = 8 waves x 32 keys)
-//
-// Counters of the 4-wave kernel above (profiles/r02_pmc_sq_*.txt): matrix pipe 27 % busy, VALU 35 %, waves 43 % of their
-// time issue-stalled - a wave's chain  S/dP MFMAs -> softmax VALU -> dV/dK MFMAs  is serial, and the co-resident waves
-// of other workgroups overlap it only by chance.  Here the overlap is built in: waves w and w+4 share a SIMD and run the
-// SAME instruction stream one barrier interval apart.  A wave alternates
-//     M(b): the 8 dV/dK MFMAs of block b-1 and the 8 S/dP MFMAs of block b   (16 x 32 cycles of matrix pipe; the 8 ds_read_b128
-//           of the S/dP operands are issued first and land under the dV/dK MFMAs)
-//     V(b): softmax of block b (exp2, dS, bf16 packing), the transposed LDS reads dV/dK need, LDS-DMA of a later tile
-// with one s_barrier after each, so in every interval one wave of a SIMD feeds the matrix pipe while its partner does
-// the vector / LDS work (MI355X_MICROARCH.md "Two waves per SIMD").  A block = 32 queries x the wave's 32 keys.
-// Q / dO tiles (64 queries) go through a 3-stage LDS ring: a stage is read during 5 consecutive intervals by the two
-// groups and refilled right after; every wave waits for its own DMA pieces one V slot later, so a tile is visible to
-// all waves three intervals before its first reader.
-// =============================================================================================
-struct TileDma8 {  // [64 rows][64 d] tile by 8 waves: one wave-instruction (8 rows = 1 KiB) per wave and tile
-  unsigned boff;  // the only per-lane state: byte offset of this lane's 16 bytes inside a whole tile
-  __device__ __forceinline__ void init(int wave, int lane, int64_t ld) {
-    const int row = wave * 8 + (lane >> 3);
-    boff = (unsigned)((row * ld + rs_logical_chunk(row, lane & 7) * 8) * 2);
-  }
-  // last tile of a sequence whose length is not a multiple of 64: rows above `last_row` are clamped (masked by the caller)
-  __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave, int lane) const {
-    const int row = wave * 8 + (lane >> 3);
-    dma16_asm(src + (int64_t)min(row, last_row) * ld + rs_logical_chunk(row, lane & 7) * 8, dst_tile + wave * 1024);
-  }
-  __device__ __forceinline__ void issue_full(char* dst_tile, const uint16_t* src, int wave) const {
-    dma16_saddr_asm(src, boff, dst_tile + wave * 1024);
-  }
-};
-
-__device__ __forceinline__ void pp_barrier() {  // slot boundary: everything of this slot has been issued and its LDS reads returned
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// ABL (timing-only builds, PLM_ATTN_ABL=<n>, results are WRONG for n >= 2): 1 = wait for every wave's LDS-DMA in each V slot
-// (the first version of the schedule), 2 = no softmax arithmetic, 3 = no MFMAs, 4 = no transposed LDS reads, 5 = no barriers.
-template <bool HAS_DOC, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv8_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                                const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv,
-                                                                int T, int nh) {
-  constexpr int QT = 64, KB = 256, NST = 3;
-  constexpr int TILE = QT * 128;           // 8 KiB
-  constexpr int STAGE = 2 * TILE + 1024;   // Q | dO | statistics (lse[64], delta[64], doc_start[64])
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
-
-  const int nkb = (T + KB - 1) / KB;
-  const int nbh = gridDim.x / nkb;
-  const int bh = blockIdx.x % nbh;
-  const int kb = blockIdx.x / nbh;  // key block 0 meets every query tile: heaviest first
-  const int h = bh % nh, b = bh / nh;
-  const int dm = nh * HD, ld = 3 * dm;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2;  // waves w and w+4 share a SIMD: group 1 runs one barrier interval behind group 0
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int kv0 = kb * KB;
-  const int kvw0 = kv0 + wave * 32;
-  const int kvrow = kvw0 + l31;
-  const bool kvalid = kvrow < T;
-  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
-  const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
-  const float* lrow = lse + ((int64_t)b * nh + h) * T;
-  const float* drow = delta + ((int64_t)b * nh + h) * T;
-  const int32_t* dsrow = doc_start + (HAS_DOC ? (int64_t)b * T : 0);
-  const float scale = 0.125f, c2 = scale * LOG2E;
-
-  bf16x8_t kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
-    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
-    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
-  }
-  const int nqt = (T + QT - 1) / QT;
-  const int jq_lo = kv0 / QT;
-  int jq_hi = nqt;
-  if (HAS_DOC) {
-    jq_hi = jq_lo;
-    while (jq_hi < nqt && __builtin_amdgcn_readfirstlane(dsrow[jq_hi * QT]) <= kv0 + KB - 1) ++jq_hi;
-  }
-  const int ntile = jq_hi - jq_lo;  // >= 1: the diagonal tiles always exist
-  const int nb = 2 * ntile;         // 32-query blocks this workgroup walks
-  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
-               "v"(vf[3]));  // every ordinary load is consumed before the first DMA is in flight
-
-  f32x16_t dk[2], dv[2];
-  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
-
-  TileDma8 dma, dmad;
-  dma.init(wave, lane, ld);
-  dmad.init(wave, lane, dm);
-  auto stage_tile = [&](int u) {  // tile u of this workgroup (query rows (jq_lo + u) * 64 ..) into ring slot u % 3
-    const int qt0 = (jq_lo + u) * QT;
-    char* dst = smem + (u % NST) * STAGE;
-    if (qt0 + QT <= T) {
-      dma.issue_full(dst, base + (int64_t)qt0 * ld, wave);
-      dmad.issue_full(dst + TILE, dobase + (int64_t)qt0 * dm, wave);
-    } else {
-      dma.issue(dst, base + (int64_t)qt0 * ld, ld, T - 1 - qt0, wave, lane);
-      dmad.issue(dst + TILE, dobase + (int64_t)qt0 * dm, dm, T - 1 - qt0, wave, lane);
-    }
-    if (wave == 0 && lane < 16) {  // 64 floats = 16 lanes x 16 bytes per statistic (T % 4 == 0 is checked on the host)
-      const int q = min(qt0 + lane * 4, T - 4);
-      dma16_asm(lrow + q, dst + 2 * TILE);
-      dma16_asm(drow + q, dst + 2 * TILE + 256);
-      if (HAS_DOC) dma16_asm(dsrow + q, dst + 2 * TILE + 512);
-    }
-  };
-  // block bi = (tile u = bi >> 1, half qb = bi & 1): is any of its queries at or below this wave's first key?
-  auto blk_q0 = [&](int bi) { return (jq_lo + (bi >> 1)) * QT + (bi & 1) * 32; };
-  auto blk_active = [&](int bi) { return bi < nb && blk_q0(bi) + 31 >= kvw0; };
-
-  bf16x8_t rq[4], rdo[4];          // row fragments of Q / dO for S / dP of the next block
-  bf16x8_t tq[2][2], tdo[2][2];    // transposed fragments of Q / dO for dK / dV of the current block
-  bf16x8_t pf[2], dsf[2];          // P and dS of the current block in B-operand layout
-  f32x16_t s, dp;
-  auto read_rows = [&](int bi) {
-    const char* sQ = smem + ((bi >> 1) % NST) * STAGE;
-    const int r = (bi & 1) * 32 + l31;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      rq[ks] = frag_rows(sQ, r, ks, hi);
-      rdo[ks] = frag_rows(sQ + TILE, r, ks, hi);
-    }
-  };
-  auto read_tr = [&](int bi) {
-    const char* sQ = smem + ((bi >> 1) % NST) * STAGE;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int rbase = (bi & 1) * 32 + s2 * 16 + 4 * hi;
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        tdo[s2][db] = frag_cols(sQ + TILE, db, rbase, lane);
-        tq[s2][db] = frag_cols(sQ, db, rbase, lane);
-      }
-    }
-  };
-  auto softmax = [&](int bi, auto mask_tag) {
-    constexpr bool MASK = decltype(mask_tag)::value;
-    const float* sL = reinterpret_cast<const float*>(smem + ((bi >> 1) % NST) * STAGE + 2 * TILE);
-    const float* sD = sL + 64;
-    const int* sDS = reinterpret_cast<const int*>(sL + 128);
-    const int qb = bi & 1, qt0 = (jq_lo + (bi >> 1)) * QT;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int ql0 = qb * 32 + 8 * g + 4 * hi;
-      const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0);  // base-2 LSE
-      const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
-      typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-      i32x4_t ds4 = {0, 0, 0, 0};
-      if (MASK && HAS_DOC) ds4 = *reinterpret_cast<const i32x4_t*>(sDS + ql0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        float p = fast_exp2(__builtin_fmaf(s[r], c2, -L4[e]));
-        if (MASK) {
-          const int qg = qt0 + ql0 + e;
-          bool ok = (kvrow <= qg) && (qg < T);
-          if (HAS_DOC) ok = ok && (kvrow >= ds4[e]);
-          p = ok ? p : 0.f;
-        }
-        const float dsv = p * (dp[r] - D4[e]);  // x 1/sqrt(hd) once, on dK, in the epilogue
-        pf[r >> 3][r & 7] = f2bf(p);
-        dsf[r >> 3][r & 7] = f2bf(dsv);
-      }
-      if (HAS_DOC && g == 1) __builtin_amdgcn_sched_barrier(0);  // keeps the statistics of all four groups from being live at once (256 VGPRs)
-    }
-  };
-
-  // ---- prologue: tiles 0 and 1 land, group 1 falls one interval behind, the first block's row fragments are read
-  stage_tile(0);
-  if (ntile > 1) stage_tile(1);
-  attn_wait_vm<0>();
-  pp_barrier();
-  if (grp == 1 && ABL != 5) pp_barrier();
-  bool act_prev = false;  // block bi-1 produced P / dS (its dV / dK MFMAs are due)
-  for (int bi = 0; bi <= nb; ++bi) {
-    // ================= M slot: matrix pipe (the 8 row-fragment reads of S / dP land under the dV / dK MFMAs) =================
-    const bool act = blk_active(bi);
-    if (act) read_rows(bi);
-    if (act_prev && ABL != 3) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dv[db] = mfma32(tdo[s2][db], pf[s2], dv[db]);   // dV^T[d][kv]
-          dk[db] = mfma32(tq[s2][db], dsf[s2], dk[db]);   // dK^T[d][kv]
-        }
-    }
-    if (act) {
-      zero16(s);
-      zero16(dp);
-      if (ABL != 3) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma32(rq[ks], kf[ks], s);       // S[q][kv]
-          dp = mfma32(rdo[ks], vf[ks], dp);    // dP[q][kv]
-        }
-      } else {
-        asm volatile("" ::"v"(rq[0]), "v"(rq[1]), "v"(rq[2]), "v"(rq[3]), "v"(rdo[0]), "v"(rdo[1]), "v"(rdo[2]), "v"(rdo[3]));
-      }
-    }
-    if (ABL != 5) pp_barrier();
-    // ================= V slot: vector + LDS + DMA =================
-    // A tile is staged 4 intervals before the first wave reads it and every wave waits for ITS pieces just before it issues
-    // the next tile's (one V slot in two): by then the DMA has had 4 intervals to land, and the barrier that follows the
-    // wait publishes it at least one interval before the first read.
-    if (ABL == 1 || !(bi & 1)) attn_wait_vm<0>();
-    if (!(bi & 1) && (bi >> 1) + 2 < ntile) stage_tile((bi >> 1) + 2);  // its ring slot was last read two intervals ago
-    if (act) {
-      if (ABL != 4) read_tr(bi);
-      const int q0 = blk_q0(bi);
-      const bool need_mask = HAS_DOC || q0 < kvw0 + 31 || q0 + 32 > T;
-      if (ABL == 2) {
-        asm volatile("" ::"v"(s), "v"(dp));
-      } else {
-        if (need_mask) softmax(bi, std::true_type{}); else softmax(bi, std::false_type{});
-      }
-    }
-    act_prev = act;
-    if (ABL != 5) pp_barrier();
-  }
-  if (grp == 0 && ABL != 5) pp_barrier();  // balances group 1's extra barrier
-  attn_wait_vm<0>();
-
-  if (kvalid) {
-    uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
-    uint16_t* dvp = dkp + dm;
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        bf16x4_t ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
-        st_bf16x4(dvp + d0, ov);
-        const float c0 = rcos[kvrow * 32 + d0 / 2], c1 = rcos[kvrow * 32 + d0 / 2 + 1];
-        const float s0 = rsin[kvrow * 32 + d0 / 2], s1 = rsin[kvrow * 32 + d0 / 2 + 1];
-        const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
-        bf16x4_t ok;
-        ok[0] = f2bf(a0 * c0 + b0 * s0);
-        ok[1] = f2bf(b0 * c0 - a0 * s0);
-        ok[2] = f2bf(a1 * c1 + b1 * s1);
-        ok[3] = f2bf(b1 * c1 - a1 * s1);
-        st_bf16x4(dkp + d0, ok);
-      }
-    }
-  }
-}
-
-// =============================================================================================
 // backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows; q, k rotated)
 // =============================================================================================
 template <bool HAS_DOC>
@@ -804,9 +555,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 // =============================================================================================
 // C ABI
 // =============================================================================================
-void plm_launch_attn_bwd_dkdv_pipe(const uint16_t* qkv, const uint16_t* dout, const float* lse, const float* delta, const float* rope_cos,
-                                   const float* rope_sin, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);  // attn_pipe.hip
-
 static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, int64_t hd) {
   PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
   PLM_REQUIRE(B > 0 && T > 0 && nh > 0 && B < 65536 && nh < 65536 && T < (1 << 24), "%s: bad shape B=%ld T=%ld nh=%ld", name, (long)B,
@@ -850,23 +598,12 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   const dim3 block(256);
   // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
   const dim3 gkv((unsigned)(plm_cdiv(T, 128) * nh * B));
-  const dim3 gkv8((unsigned)(plm_cdiv(T, 256) * nh * B)), block8(512);
-  static const bool v1 = getenv("PLM_ATTN_BWD_V1") != nullptr;  // A/B: the 4-wave dK/dV kernel
   if (doc_start) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    static const bool v8 = getenv("PLM_ATTN_DKDV8") != nullptr;  // A/B: the 8-wave ping-pong kernel
-    if (v1) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    else if (!v8 && T % 128 == 0) plm_launch_attn_bwd_dkdv_pipe(qkv, dout, lse, delta, rope_cos, rope_sin, dqkv, B, T, nh, s);
-    else if (!v8) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    else {
-      static const int abl = getenv("PLM_ATTN_ABL") ? atoi(getenv("PLM_ATTN_ABL")) : 0;
-#define PLM_DKDV8(A) hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<false, A>), gkv8, block8, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh)
-      if (abl == 1) PLM_DKDV8(1); else if (abl == 2) PLM_DKDV8(2); else if (abl == 3) PLM_DKDV8(3); else if (abl == 4) PLM_DKDV8(4); else if (abl == 5) PLM_DKDV8(5); else PLM_DKDV8(0);
-#undef PLM_DKDV8
-    }
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
   }
   PLM_CHECK_LAUNCH("plm_attn_bwd");
   return PLM_OK;

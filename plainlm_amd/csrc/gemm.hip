@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const uint16_t* __rest
 }
 
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
-                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
-                            int rope_T, int rope_cols, void* workspace, size_t workspace_bytes, hipStream_t s);  // gemm_big.hip
+                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, void* workspace, size_t workspace_bytes,
+                            hipStream_t s);  // gemm_big.hip
 extern "C" int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                            void* stream);
 
@@ -310,7 +310,7 @@ extern "C" int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_
                                    int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   PLM_REQUIRE(A && B && C, "plm_gemm_bf16_nt: null pointer");
-  PLM_REQUIRE(variant >= 0 && variant <= 18, "plm_gemm_bf16_nt_ex: variant must be 0..18");
+  PLM_REQUIRE(variant >= 0 && variant <= 6, "plm_gemm_bf16_nt_ex: variant must be 0..6");
   PLM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "plm_gemm_bf16_nt: bad shape M=%ld N=%ld K=%ld",
               (long)M, (long)N, (long)K);
   PLM_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "plm_gemm_bf16_nt: K, lda, ldb must be multiples of 8 and ldc of 4 (K=%ld lda=%ld ldb=%ld ldc=%ld)",
@@ -328,8 +328,7 @@ extern "C" int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_
   PLM_REQUIRE(variant <= 2 || c_dtype == 0, "plm_gemm_bf16_nt_ex: the big-tile variants write bf16 C only");
   const bool dma_ok = variant >= 2 || (variant == 0 && !force_v1 && dma_shape);
   if ((variant == 0 && dma_ok && c_dtype == 0) || variant >= 3) {
-    if (plm_launch_gemm_nt_big(variant, A, lda, B, ldb, (uint16_t*)C, ldc, M, N, K, alpha_dev, nullptr, nullptr, 0, 0, workspace,
-                               workspace_bytes, s)) {
+    if (plm_launch_gemm_nt_big(variant, A, lda, B, ldb, (uint16_t*)C, ldc, M, N, K, alpha_dev, workspace, workspace_bytes, s)) {
       PLM_CHECK_LAUNCH("plm_gemm_bf16_nt (big tile)");
       return PLM_OK;
     }
@@ -361,26 +360,16 @@ extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* 
   return plm_gemm_bf16_nt_ws(A, lda, B, ldb, C, ldc, M, N, K, c_dtype, accumulate, alpha_dev, 0, nullptr, 0, stream);
 }
 
-// w_qkv projection with RoPE: qkv[M, 3*nh*hd] = x W^T, then the q | k column blocks are rotated (row m = position m % T).
-// The rotation runs in the GEMM epilogue (fp32, before the bf16 rounding) whenever the persistent big-tile kernel takes
-// the shape; otherwise the plain GEMM is followed by the in-place plm_rope_qk pass.  Same result layout either way.
+// w_qkv projection with RoPE: qkv[M, 3*nh*hd] = x W^T, then the q | k column blocks are rotated in place (row m = position
+// m % T) by the one-pass plm_rope_qk kernel.  (Round 1 also had the rotation in the GEMM epilogue: the epilogue is not
+// overlapped with MFMA work and its table loads cost 58 us per call against 31 us for the separate pass, run 23 - removed.)
 extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* QKV, int64_t ldq, int64_t M,
                                  int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                                  void* stream) {
   PLM_REQUIRE(X && W && QKV && rope_cos && rope_sin, "plm_qkv_rope_bf16: null pointer");
   PLM_REQUIRE(hd == 64 && B > 0 && T > 0 && nh > 0 && M == B * T, "plm_qkv_rope_bf16: bad shape (hd must be 64, M == B*T)");
   const int64_t N = 3 * nh * hd;
-  hipStream_t s = (hipStream_t)stream;
-  // measured (run 23): the rotation in the GEMM epilogue is not overlapped with MFMA work and its 64 table loads per lane and
-  // tile cost ~58 us per call against 31 us for the separate in-place pass, so the fused epilogue is opt-in (PLM_FUSED_ROPE=1)
-  const bool fused_ok = getenv("PLM_FUSED_ROPE") != nullptr && (K % GBK == 0) && (ldq % 8 == 0) && ldx % 8 == 0 && ldw % 8 == 0 &&
-                        (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(QKV)) & 15) == 0);
-  if (fused_ok &&
-      plm_launch_gemm_nt_big(0, X, ldx, W, ldw, QKV, ldq, M, N, K, nullptr, rope_cos, rope_sin, (int)T, (int)(2 * nh * hd), nullptr, 0, s)) {
-    PLM_CHECK_LAUNCH("plm_qkv_rope_bf16 (fused epilogue)");
-    return PLM_OK;
-  }
-  PLM_REQUIRE(ldq == N, "plm_qkv_rope_bf16: the unfused path needs a dense output (ldq == 3*nh*hd)");
+  PLM_REQUIRE(ldq == N, "plm_qkv_rope_bf16: needs a dense output (ldq == 3*nh*hd)");
   if (int rc = plm_gemm_bf16_nt_ex(X, ldx, W, ldw, QKV, ldq, M, N, K, 0, 0, nullptr, 0, stream)) return rc;
   return plm_rope_qk(QKV, rope_cos, rope_sin, B, T, nh, hd, stream);
 }

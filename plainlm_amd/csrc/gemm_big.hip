@@ -78,15 +78,7 @@ static double round_efficiency(int64_t tiles, int slots) {
 // STAG: every phase is split into a READ section (DMA issue, ds_reads, counted vmcnt wait) and an MFMA section with a
 // barrier after each; the wave group wm-odd runs one barrier behind the other (waves w and w+4 share a SIMD and sit in
 // different groups), so one group's LDS reads overlap the other group's MFMAs; s_setprio(1) around the MFMA cluster.
-// ROPE: the epilogue applies the interleaved-pair rotary embedding (models/embeddings.py:15-30) to the output
-// columns [0, rope_cols) before the bf16 rounding: row m is token position m % rope_T, column n is head dim n % 64,
-// pair (n, n+1) rotates by the angle of rope tables [T][32].  Used for the w_qkv projection (q | k blocks).
-struct RopeArgs {
-  const float* cos_t;
-  const float* sin_t;
-  int T;
-  int cols;
-};
+// Used by the hybrid (whole-K + stream-K) launch of the long-K lm_head dX GEMM, where it is the fastest schedule in the step.
 // Hybrid work items: the tiles of the first `rfull` tile rows take the whole contraction and write bf16 C (whole
 // rounds of the persistent grid); the K-tiles of the remaining tile rows form ONE stream (tile-major, then k) that is
 // cut into `nchunks` equal runs of `L` K-tiles, one run per workgroup ("stream-K" for the last, partial round).  A run
@@ -101,19 +93,16 @@ struct HybridArgs {
   float* slabs;
 };
 
-// ONEBAR: all four half-tiles of the next K-tile are issued at the top of the current one and the quadrants run
-// back-to-back with a single s_waitcnt vmcnt(0) + barrier per K-tile (the compiler is then free to interleave the
-// ds_reads of later quadrants with the MFMAs of earlier ones).
 // DEEP (4-phase schedule only): a half-tile slot is refilled as soon as the phase that read it has ended, with the
 // half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups
 // (80 KiB for 256x256) are in flight behind every counted wait instead of two.  Measured (profiles/r01_kbench_run19*):
 // global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deeper queue lets them overlap.
-template <int BM, int BN, int WM, int WN, bool STAG, bool ROPE, bool ONEBAR = false, bool HYB = false, bool DEEP = false, bool P2 = false, bool OFFS = false>
+template <int BM, int BN, int WM, int WN, bool STAG, bool HYB = false, bool DEEP = false, bool OFFS = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
-                                                             RopeArgs rope, HybridArgs hyb) {
+                                                             HybridArgs hyb) {
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   static_assert(WM * WN == 8 && (TN == 64 || TN == 96) && (TM == 128 || TM == 64), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
@@ -130,29 +119,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   constexpr int W_P4 = A_DMA + B1_DMA;  // end of phase 4: B1', A1' may stay in flight
   constexpr int W_P1 = 2 * A_DMA;       // end of phase 1: A1', A0'' may stay in flight
   constexpr int W_P2 = A_DMA + B0_DMA;  // end of phase 2: A0'', B0'' may stay in flight
-  static_assert(!DEEP || (!STAG && !ONEBAR), "DEEP is a variant of the plain 4-phase schedule");
+  static_assert(!DEEP || !STAG, "DEEP is a variant of the plain 4-phase schedule");
   // DEEP: groups younger than the one a wait retires (see the schedule above)
   constexpr int D_P4 = 2 * A_DMA + B0_DMA + 2 * B1_DMA;  // end of phase 4 -> A0, B0 of kt+1: B1', A1', A0'', B0'', B1'' in flight
   constexpr int D_P1 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 1 -> B1 of kt: A1, A0', B0', B1', A1' in flight
   constexpr int D_P2 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 2 -> A1 of kt: A0', B0', B1', A1', A0'' in flight
-  // P2 (two-phase form of DEEP): phase A = quadrants (A0,B0),(A0,B1), phase B = (A1,B1),(A1,B0); two barriers per K-tile, each
-  // merged with a counted wait.  Barrier A (all reads of A0/B0/B1 done, A1 of this K-tile landed) is followed by ALL the DMA
-  // issue of the K-tile: A1 of kt+1, then A0, B0, B1 of kt+2 into the slots just released; barrier B waits for A0, B0, B1 of kt+1.
-  static_assert(!P2 || DEEP, "P2 is a variant of the deep-prefetch ring");
   // OFFS (offset wave groups, deep ring only): waves w and w+4 share a SIMD.  With every wave on the same schedule both do their
   // DMA issue + LDS reads at the same time and then queue for the matrix pipe: a phase costs overhead + 2 x MFMA time.  Here the
   // second group (waves 4-7) takes each barrier BETWEEN the reads and the MFMAs of a phase instead of behind the MFMAs - same
   // code, same three barriers per K-tile and wave, same slots and waits - so inside every barrier interval group 0 runs
   // reads(p), MFMAs(p) while group 1 runs MFMAs(p-1), reads(p): one wave's reads and DMA issue sit under the other's MFMAs.
-  static_assert(!OFFS || (DEEP && !P2), "OFFS is a variant of the 4-phase deep-prefetch ring");
-  constexpr int P_WA = A_DMA + B0_DMA + B1_DMA;      // A0', B0', B1' may stay in flight
-  constexpr int P_WB = 2 * A_DMA + B0_DMA + B1_DMA;  // A1', A0'', B0'', B1'' may stay in flight
+  static_assert(!OFFS || DEEP, "OFFS is a variant of the 4-phase deep-prefetch ring");
   // DEEP: the C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
   constexpr int NS = 2 * AF * 2 * NBF;
   static_assert(!DEEP || D_P1 + NS < 64, "vmcnt is a 6-bit counter");
-  static_assert(!P2 || P_WB + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -214,11 +196,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   };
 
   // ---- source pointers of the item being staged (one K-tile of one output tile) ----
-  // LDS-DMA addresses.  ONEBAR kernels: wave-uniform base of the staged tile (SGPR pair; the K offset is added there) + per-lane
-  // unsigned byte offsets inside the tile's row panel (<= 256 rows) - no 64-bit VALU add, half the address registers per
-  // instruction: 3-5 % faster (run 27).  The 4-phase kernels keep per-lane 64-bit pointers and the builtin (the asm form
-  // measured 1 % slower there: two instructions per phase leave hipcc nothing to schedule around).
-  constexpr bool SADDR = ONEBAR;
+  // LDS-DMA addresses: wave-uniform base of the staged K-tile (SGPR pair, running pointers) + per-lane unsigned byte offsets
+  // inside the tile's row panel, issued through the builtin (the inline-asm form measured 1 % slower in the 4-phase kernels:
+  // two instructions per phase leave hipcc nothing to schedule around).
   unsigned oa[2][A_DMA], ob[2][B0_DMA];
   const uint16_t* s_ab = A;
   const uint16_t* s_bb = B;
@@ -253,8 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
       (void)k0;
-      if (SADDR) dma16_saddr_asm(s_ak, oa[h][i], dst + (i * 8 + wave) * 1024);
-      else big_dma16(reinterpret_cast<const char*>(s_ak) + oa[h][i], dst + (i * 8 + wave) * 1024);  // uniform base + zext(lane offset)
+      big_dma16(reinterpret_cast<const char*>(s_ak) + oa[h][i], dst + (i * 8 + wave) * 1024);  // uniform base + zext(lane offset)
     }
   };
   auto issue_b = [&](int h, char* stage, int k0) {
@@ -263,8 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     for (int i = 0; i < B0_DMA; ++i) {
       if (i >= (h ? B1_DMA : B0_DMA)) continue;
       (void)k0;
-      if (SADDR) dma16_saddr_asm(s_bk, ob[h][i], dst + (i * 8 + wave) * 1024);
-      else big_dma16(reinterpret_cast<const char*>(s_bk) + ob[h][i], dst + (i * 8 + wave) * 1024);
+      big_dma16(reinterpret_cast<const char*>(s_bk) + ob[h][i], dst + (i * 8 + wave) * 1024);
     }
   };
   auto frag = [&](const char* ht, int row, int ks) -> bf16x8_t {
@@ -319,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     issue_a(0, smem + STAGE, s_k);
     issue_b(0, smem + STAGE, s_k);
     issue_b(1, smem + STAGE, s_k);
-    wait_vm<P2 ? A_DMA + P_WA : D_P4>();  // P2: phase A reads B1 as well - only A1 and the second K-tile's pieces stay in flight
+    wait_vm<D_P4>();
   } else {
     wait_vm<0>();
   }
@@ -353,65 +331,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a[AF][4], b0[BF0][4], b1[4];
-      if (P2) {
-        // ---- phase A: reads A0, B0, B1
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-          for (int j = 0; j < BF0; ++j) b0[j][ks] = frag(cur + OFF_B0, (wn * BF0 + j) * 32 + l31, ks);
-#pragma unroll
-          for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
-          b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
-        }
-        if (!more) wait_vm<0>();
-        else if (credit) wait_vm<P2 ? P_WA + NS : 0>();
-        else wait_vm<P_WA>();
-        phase_barrier();
-        if (more) {
-          issue_a(1, smem + s_st * STAGE, s_k);
-          advance_staged();
-          more = DEEP || s_item < ntiles;
-        }
-        if (more) {
-          issue_a(0, smem + s_st * STAGE, s_k);
-          issue_b(0, smem + s_st * STAGE, s_k);
-          issue_b(1, smem + s_st * STAGE, s_k);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int f = 0; f < AF; ++f) {
-#pragma unroll
-            for (int j = 0; j < BF0; ++j) acc[f][j] = mfma32(b0[j][ks], a[f][ks], acc[f][j]);
-            acc[f][BF0] = mfma32(b1[ks], a[f][ks], acc[f][BF0]);
-          }
-        // ---- phase B: reads A1
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A1, wm * AH + f * 32 + l31, ks);
-        if (!more) wait_vm<0>();
-        else if (credit) wait_vm<P2 ? P_WB + NS : 0>();
-        else wait_vm<P_WB>();
-        phase_barrier();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int f = 0; f < AF; ++f) {
-            acc[AF + f][BF0] = mfma32(b1[ks], a[f][ks], acc[AF + f][BF0]);
-#pragma unroll
-            for (int j = 0; j < BF0; ++j) acc[AF + f][j] = mfma32(b0[j][ks], a[f][ks], acc[AF + f][j]);
-          }
-        credit = false;
-        credit_i = 0;
-        st ^= 1;
-        continue;
-      }
-
       // end of a phase's READ section / MFMA section
       auto end_read = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
-        if (ONEBAR) return;
         // one scalar compare on the common path (the nested form cost ~10 scalar instructions and three branches per wait)
         if (!more) wait_vm<0>();
         else if (DEEP) wait_vm_sel<W, DEEP ? W + NS : W>(credit_i);
@@ -423,12 +345,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           phase_barrier();
         }
       };
-      if (ONEBAR && more) {  // the whole next K-tile goes in flight now
-        issue_a(0, nxt, s_k);
-        issue_b(0, nxt, s_k);
-        issue_b(1, nxt, s_k);
-        issue_a(1, nxt, s_k);
-      }
       auto end_mfma = [&]() {
         if (STAG) {
           __builtin_amdgcn_s_setprio(0);
@@ -444,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           advance_staged();
           more = DEEP || s_item < ntiles;
         }
-      } else if (!ONEBAR && !STAG && more) {
+      } else if (!STAG && more) {
         issue_a(0, nxt, s_k);
       }
 #pragma unroll
@@ -470,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       // ---- phase 2: quadrant (A0, B1); stage B0 (DEEP: A0 two K-tiles ahead, into the slot phase 1 just read)
       if (DEEP) {
         if (more) issue_a(0, smem + s_st * STAGE, s_k);
-      } else if (!ONEBAR && !STAG && more) {
+      } else if (!STAG && more) {
         issue_b(0, nxt, s_k);
       }
 #pragma unroll
@@ -489,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       // ---- phase 3: quadrant (A1, B1); stage B1 (DEEP: B0).  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
       if (DEEP) {
         if (more) issue_b(0, smem + s_st * STAGE, s_k);
-      } else if (!ONEBAR && !STAG && more) {
+      } else if (!STAG && more) {
         issue_b(1, nxt, s_k);
       }
 #pragma unroll
@@ -511,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1 (DEEP: B1)
       if (DEEP) {
         if (more) issue_b(1, smem + s_st * STAGE, s_k);
-      } else if (!ONEBAR && more) {
+      } else if (more) {
         issue_a(1, nxt, s_k);
       }
       if (STAG) {
@@ -526,10 +442,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           for (int j = 0; j < BF0; ++j) acc[AF + f][j] = mfma32(b0[j][ks], a[f][ks], acc[AF + f][j]);
       if (STAG) {
         end_mfma();
-      } else if (ONEBAR) {
-        if (more) advance_staged();
-        wait_vm<0>();
-        phase_barrier();
       } else {
         if (!DEEP && more) advance_staged();
         if (!grp1) end_read(integral_constant<int, DEEP ? D_P4 : W_P4>{});
@@ -565,7 +477,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
-      const int tpos = ROPE ? (mrow0 + l31) % rope.T : 0;  // token position of this lane's row
       // the wave's TN columns leave in passes of up to 64 (TN = 96: 64 + 32)
 #pragma unroll
       for (int p0 = 0; p0 < NBF; p0 += 2) {
@@ -577,27 +488,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             bf16x4_t o;
-            if (ROPE) {
-              const int ncol = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns
-              float v0 = acc[mf][bh][4 * g + 0] * alpha, v1 = acc[mf][bh][4 * g + 1] * alpha;
-              float v2 = acc[mf][bh][4 * g + 2] * alpha, v3 = acc[mf][bh][4 * g + 3] * alpha;
-              if (ncol < rope.cols) {
-                const int pi = tpos * 32 + (ncol & 63) / 2;  // even: the two pairs' table entries are one aligned 8-byte load each
-                typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-                const f32x2_t cc = *reinterpret_cast<const f32x2_t*>(rope.cos_t + pi);
-                const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(rope.sin_t + pi);
-                const float c0 = cc[0], c1 = cc[1], s0 = ss[0], s1 = ss[1];
-                const float a0 = v0, b0 = v1, a1 = v2, b1 = v3;
-                v0 = a0 * c0 - b0 * s0;
-                v1 = b0 * c0 + a0 * s0;
-                v2 = a1 * c1 - b1 * s1;
-                v3 = b1 * c1 + a1 * s1;
-              }
-              o[0] = f2bf(v0); o[1] = f2bf(v1); o[2] = f2bf(v2); o[3] = f2bf(v3);
-            } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
-            }
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
             const int c = bq * 4 + g;  // 16-byte chunk of the pass's row; this lane fills half `hi` of it
             *reinterpret_cast<bf16x4_t*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4) + hi * 8) = o;
           }
@@ -998,8 +890,7 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const dim3 grid(nitems < slots ? nitems : slots), block(512);
   // deep-prefetch ring + offset wave groups (see gemm_nt_big_kernel): each alone measured equal to the plain ring in the step, together
   // +0.8 % end to end (run 34); PLM_TN_NO_DEEP / PLM_TN_NO_OFFS bring the other forms back for A/B runs
-  static const bool deep = getenv("PLM_TN_NO_DEEP") == nullptr;
-  static const bool offs = getenv("PLM_TN_NO_OFFS") == nullptr;
+  const bool deep = true, offs = true;  // deep-prefetch ring + offset wave groups (+0.8 % end to end, run 34)
   if (offs && !deep)
     hipLaunchKernelGGL((gemm_tn_big_kernel<false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
                        rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
@@ -1077,15 +968,6 @@ static bool tn_group_plan(const int64_t* Ms, const int64_t* Ns, int count, int64
   g->count = count;
   const int64_t nkt = K / 64, total = (int64_t)base * nkt;
   const int slots = persistent_slots();
-  if (getenv("PLM_TN_GROUP_STREAMK") != nullptr) {  // measured slower (run 25): tile-major runs share no operand panels in L2
-    int64_t L = plm_cdiv(total, slots);
-    if (L < 4) L = 4;  // a run this short is all prologue
-    g->L = (int)L;
-    g->nchunks = (int)plm_cdiv(total, L);
-    g->splits = 0;
-    *nslabs = (int)((nkt - 1) / L + 2);
-    return total < (1ll << 30);
-  }
   // uniform split-K over all problems: the number of splits whose item count fills whole rounds best, >= 8 K-tiles each
   int best = 1;
   double best_eff = 0.0;
@@ -1143,7 +1025,7 @@ extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, 
     return PLM_E_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  static const bool offs = getenv("PLM_TN_NO_OFFS") == nullptr, deep = getenv("PLM_TN_NO_DEEP") == nullptr;
+  const bool offs = true, deep = true;
   if (offs && deep)
     hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
                        (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
@@ -1232,12 +1114,12 @@ extern "C" size_t plm_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 // variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered,
 // 7 / 8 = the same with one barrier per K-tile
-void plm_launch_gemm_nt_w4(int slots, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
-                           int64_t N, int64_t K, const float* alpha_dev, hipStream_t s);  // gemm_w4.hip
-
+// variant: 0 automatic | 3 plain 4-phase ring, 256x256 | 4 / 5 / 6 deep-prefetch ring with offset wave groups on 256x256 / 256x192 /
+// 256x128 tiles (what the automatic policy picks from; explicit numbers exist for the tests and tools/kbench.py).
+// Returns false when the shape is better served by the 128x128 kernels of gemm.hip.
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
-                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, const float* rope_cos, const float* rope_sin,
-                            int rope_T, int rope_cols, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                            int64_t M, int64_t N, int64_t K, const float* alpha_dev, void* workspace, size_t workspace_bytes,
+                            hipStream_t s) {
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1247,19 +1129,17 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const int tm = (int)plm_cdiv(M, 256);
   const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
   const int slots = persistent_slots();
+  // tile shape = round efficiency on the persistent grid x a measured per-tile rate (1 / 0.94 / 0.88): 256x192 has 22 % fewer
+  // LDS-DMA bytes and 17 % fewer LDS reads per MFMA than 256x128, and N = 768 is four 192-column tiles = exactly two rounds at
+  // M = 32768; 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape
   const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
-  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * (getenv("PLM_E128") ? atof(getenv("PLM_E128")) : 0.88);  // lower intensity (measured: 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape)
-  // 256x192 (wave tile 64x96): 22 % fewer LDS-DMA bytes and 17 % fewer LDS reads per MFMA than 256x128; N = 768 is 4 tile
-  // columns = exactly two rounds of 256 CUs at M = 32768
-  static const double f192 = getenv("PLM_E192") ? atof(getenv("PLM_E192")) : 0.94;
-  const double e192 = round_efficiency((int64_t)tm * tn192, slots) * ((double)N / (tn192 * 192.0)) * f192;
-  // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
-  // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
+  const double e192 = round_efficiency((int64_t)tm * tn192, slots) * ((double)N / (tn192 * 192.0)) * 0.94;
+  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.88;
   const dim3 block(512);
-  const RopeArgs rope{rope_cos, rope_sin, rope_T, rope_cols};
   const HybridArgs hyb{tm, 0, 1, nullptr};  // plain schedule
-  // hybrid whole-K + stream-K schedule on 256x256 tiles (automatic choice only; needs the caller's fp32 workspace)
-  if (variant == 0 && !rope_cos && workspace) {
+  // long K with a badly quantised tile count (lm_head dX: 384 tiles on 256 CUs): whole-K tiles for the full rounds + stream-K
+  // over the remaining tile rows, on the staggered schedule (needs the caller's fp32 workspace)
+  if (variant == 0 && workspace) {
     NtHybridPlan p;
     if (plm_nt_hybrid_plan(M, N, K, &p)) {
       const int64_t rem_rows = M - (int64_t)p.rfull * 256;
@@ -1268,19 +1148,8 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         const HybridArgs h{p.rfull, p.nchunks, p.L, (float*)workspace};
         const int nitems = p.rfull * tn256 + p.nchunks;
         const dim3 g2(nitems < slots ? nitems : slots);
-        const bool ob = K <= 2304 && getenv("PLM_GEMM_ONEBAR") != nullptr;
-        if (ob)
-          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                             (int)K, alpha_dev, tm, tn256, rope, h);
-        else if (getenv("PLM_HYB_OFFS") != nullptr)
-          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true, true, false, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                             (int)K, alpha_dev, tm, tn256, rope, h);
-        else if (getenv("PLM_HYB_DEEP") != nullptr)
-          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                             (int)K, alpha_dev, tm, tn256, rope, h);
-        else  // staggered wave groups: the fastest long-K schedule since the DMA addresses went to the SGPR-base form (run 28)
-          hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true, false, false, true, false>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                             (int)K, alpha_dev, tm, tn256, rope, h);
+        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true, true, false, false>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                           (int)K, alpha_dev, tm, tn256, h);
         const int64_t nv = rem_rows * (N / 8);
         int64_t rb = plm_cdiv(nv, 256);
         if (rb > 4096) rb = 4096;
@@ -1290,129 +1159,30 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
       }
     }
   }
+  // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
+  // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
-  if (variant == 10 || variant == 11) {  // deep-prefetch 4-phase schedule, 256x256 / 256x128
-    const RopeArgs nr{nullptr, nullptr, 0, 0};
-    const int tn_ = variant == 10 ? tn256 : tn128;
-    const int nt_ = tm * tn_;
-    const dim3 g(nt_ < slots ? nt_ : slots);
-    if (variant == 10)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    else
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
+  if (variant == 3) {
+    const int nt_ = tm * tn256;
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false>), dim3(nt_ < slots ? nt_ : slots), block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
+                       (int)N, (int)K, alpha_dev, tm, tn256, hyb);
     return true;
   }
-  static const int p2_max_k = getenv("PLM_GEMM_P2") ? atoi(getenv("PLM_GEMM_P2")) : 0;  // two-phase ring for K <= this (A/B knob)
-  const bool env_p2 = K <= p2_max_k;
-  static const bool env_offs = getenv("PLM_GEMM_NO_OFFS") == nullptr;  // default since run 33 (+0.9 % end to end); PLM_GEMM_NO_OFFS=1 for A/B
-  if ((variant >= 16 && variant <= 18) || (variant == 0 && env_offs && !rope_cos)) {  // deep ring with offset wave groups
-    const RopeArgs nr{nullptr, nullptr, 0, 0};
-    int which = variant - 16;  // 0: 256x256, 1: 256x192, 2: 256x128
-    if (variant == 0) which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
-    const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
-    const int nt_ = tm * tn_;
-    const dim3 g(nt_ < slots ? nt_ : slots);
-    if (which == 0)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc,
-                         (int)M, (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    else if (which == 1)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc,
-                         (int)M, (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    else
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc,
-                         (int)M, (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    return true;
-  }
-  if (variant >= 13 && variant <= 15) {  // two-phase deep-prefetch ring: 256x256 / 256x192 / 256x128
-    const RopeArgs nr{nullptr, nullptr, 0, 0};
-    const int tn_ = variant == 13 ? tn256 : variant == 14 ? tn192 : tn128;
-    const int nt_ = tm * tn_;
-    const dim3 g(nt_ < slots ? nt_ : slots);
-    if (variant == 13)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    else if (variant == 14)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    else
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn_, nr, hyb);
-    return true;
-  }
-  if (variant == 12 || (variant == 0 && !rope_cos && e192 > e256 && e192 > e128 && M >= 512 && getenv("PLM_NO_192") == nullptr)) {
-    const int nt_ = tm * tn192;
-    const dim3 g(nt_ < slots ? nt_ : slots);
-    if (variant == 0 && env_p2) {
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn192, RopeArgs{nullptr, nullptr, 0, 0}, hyb);
-      return true;
-    }
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                       (int)N, (int)K, alpha_dev, tm, tn192, RopeArgs{nullptr, nullptr, 0, 0}, hyb);
-    return true;
-  }
-  if (variant == 9) {  // one wave per SIMD, 128x128 per wave (gemm_w4.hip); whole tiles only, other shapes run as variant 3
-    if (M % 256 == 0 && N % 256 == 0) {
-      plm_launch_gemm_nt_w4(slots, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, s);
-      return true;
-    }
-    variant = 3;
-  }
-  // Automatic schedule, decided INSIDE the training step (bench.py A/Bs of run 28; these kernels are power-limited and the
-  // isolated benchmark on N(0,1) data ranks the schedules differently):
-  //  * the deep-prefetch 4-phase ring for every K and both tile shapes: since the LDS-DMA addresses use the SGPR-base form it
-  //    beats the one-barrier schedule even at K = 768 (828.7 -> 850.6 K tok/s end to end with everything on it);
-  //  * staggered wave groups only in the hybrid lm_head dX launch (2.25 -> 2.02 ms in-step) - as the general long-K choice they
-  //    lost 1 % end to end although they are the fastest variant on square N(0,1) problems (1190 / 1326 TF at 4096^3 / 8192^3);
-  //  * PLM_GEMM_ONEBAR=1 / PLM_GEMM_STAG=1 bring the other schedules back for A/B runs (variants 5-8 select them explicitly).
-  static const bool env_onebar = getenv("PLM_GEMM_ONEBAR") != nullptr, env_stag = getenv("PLM_GEMM_STAG") != nullptr;
-  const bool auto_stag = env_stag && !rope_cos && e256 >= e128;
-  const bool auto_onebar = env_onebar && K <= 2304 && !auto_stag;
-  const bool use256 = variant == 3 || variant == 5 || variant == 7 || (variant == 0 && e256 >= e128);
-  const bool stag = variant == 5 || variant == 6 || (variant == 0 && auto_stag);
-  const bool onebar = variant == 7 || variant == 8 || (variant == 0 && auto_onebar);
-  const int ntiles = tm * (use256 ? tn256 : tn128);
-  const dim3 grid(ntiles < slots ? ntiles : slots);
-#define PLM_NTB(BN_, WM_, WN_, ST_, RP_, TN_)                                                                                          \
-  hipLaunchKernelGGL((gemm_nt_big_kernel<256, BN_, WM_, WN_, ST_, RP_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, \
-                     alpha_dev, tm, TN_, rope, hyb)
-  if (rope_cos) {  // fused-RoPE epilogue (non-staggered schedules only)
-    if (onebar) {
-      if (use256)
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                           (int)K, alpha_dev, tm, tn256, rope, hyb);
-      else
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                           (int)K, alpha_dev, tm, tn128, rope, hyb);
-    } else if (use256) PLM_NTB(256, 2, 4, false, true, tn256); else PLM_NTB(128, 4, 2, false, true, tn128);
-  } else if (onebar) {
-    if (use256)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                         (int)K, alpha_dev, tm, tn256, rope, hyb);
-    else
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                         (int)K, alpha_dev, tm, tn128, rope, hyb);
-  } else if (use256) {
-    if (stag) PLM_NTB(256, 2, 4, true, false, tn256);
-    else if (variant == 0 && env_p2)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn256, rope, hyb);
-    else if (variant == 0)  // automatic long-K choice: the deep-prefetch form of the 4-phase schedule (2-6 % faster, run 19)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn256, rope, hyb);
-    else PLM_NTB(256, 2, 4, false, false, tn256);
-  } else {
-    if (stag) PLM_NTB(128, 4, 2, true, false, tn128);
-    else if (variant == 0 && env_p2)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn128, rope, hyb);
-    else if (variant == 0)
-      hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, alpha_dev, tm, tn128, rope, hyb);
-    else PLM_NTB(128, 4, 2, false, false, tn128);
-  }
-#undef PLM_NTB
+  // the automatic schedule, decided INSIDE the training step (bench.py A/Bs of runs 28-33): the deep-prefetch 4-phase ring with
+  // offset wave groups for every K and all three tile shapes
+  int which = variant - 4;  // 0: 256x256, 1: 256x192, 2: 256x128
+  if (variant == 0) which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
+  const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
+  const int nt_ = tm * tn_;
+  const dim3 g(nt_ < slots ? nt_ : slots);
+  if (which == 0)
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                       (int)K, alpha_dev, tm, tn_, hyb);
+  else if (which == 1)
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                       (int)K, alpha_dev, tm, tn_, hyb);
+  else
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                       (int)K, alpha_dev, tm, tn_, hyb);
   return true;
 }

@@ -8,8 +8,6 @@ buffer through a ``GradSink`` (our engine; enables bucketed RCCL all-reduce that
 overlaps the rest of backward).
 """
 
-import os
-
 import torch
 
 from . import ops
@@ -29,7 +27,7 @@ class GradSink:
     # Weight gradients of bias-free Linears have no consumer inside backward, so they are queued and issued `dw_group` at a
     # time (= the four projections of one transformer block) as ONE grouped split-K launch (ops.gemm_tn_grouped): whole
     # rounds of work items on all CUs and one reduce instead of four (measured -8 % on the block's dW time).
-    self.dw_group = int(os.environ.get('PLM_DW_GROUP', '4'))
+    self.dw_group = 4
     self.dw_queue = []
 
   def begin_window(self):

@@ -236,7 +236,8 @@ def _tn_workspace(nbytes, device):
 
 def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, variant=0):
   """C[M,N] = alpha * A[M,K] @ B[N,K]^T ; A, B bf16 (row stride may exceed K).
-  variant: 0 auto | 1 128x128 register-staged | 2 128x128 LDS-DMA | 3 persistent 256x256 | 4 persistent 256x128."""
+  variant: 0 auto | 1 128x128 register-staged | 2 128x128 LDS-DMA | 3 persistent 256x256, plain 4-phase ring |
+  4 / 5 / 6 persistent 256x256 / 256x192 / 256x128, deep-prefetch ring with offset wave groups (what auto picks from)."""
   for t, n in ((A, 'A'), (B, 'B')):
     if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
       raise ValueError(f'gemm_nt.{n}: need a 2-D bf16 GPU tensor with unit inner stride')
@@ -333,7 +334,7 @@ def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
 
 
 def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
-  """qkv[M, 3d] = x @ w_qkv^T with q | k rotated (RoPE fused into the GEMM epilogue when the shape allows)."""
+  """qkv[M, 3d] = x @ w_qkv^T with q | k rotated (projection GEMM + the one-pass in-place RoPE kernel)."""
   _need(x, BF16, 'qkv_rope.x', 2)
   _need(w_qkv, BF16, 'qkv_rope.w', 2)
   M, K = x.shape

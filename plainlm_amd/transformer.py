@@ -283,8 +283,6 @@ class Transformer(nn.Module):
   def refresh_shadows(self):
     """Re-cast every stale bf16 weight shadow in ONE launch (the per-Linear casts are launch-latency bound: 49 launches of
     1 - 6 MB at the 160M size).  Called at the top of every forward; HipLinear.shadow() stays as the lazy fallback."""
-    if os.environ.get('PLM_NO_MULTI_CAST'):  # A/B knob: back to one cast launch per Linear at its first use
-      return
     if self._linears is None:
       seen, self._linears = set(), []
       for m in self.modules():

@@ -89,7 +89,7 @@ def main():
         rec(name + ' [no hybrid]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
         del os.environ['PLM_NT_NO_HYBRID']
       if k % 64 == 0 and a.variants:
-        for v, vn in ((2, 'dma128'), (3, 'big256x256'), (4, 'big256x128'), (7, 'onebar256x256'), (8, 'onebar256x128'), (10, 'deep256x256'), (11, 'deep256x128'), (12, 'deep256x192'), (13, 'p2_256x256'), (14, 'p2_256x192'), (15, 'p2_256x128'), (16, 'offs256x256'), (17, 'offs256x192'), (18, 'offs256x128'), (5, 'stag256x256'), (6, 'stag256x128')):
+        for v, vn in ((2, 'dma128'), (3, 'plain256x256'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
         rec(f'{name} [auto again]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
       if k % 64 == 0 and a.instep and n < 10000:
@@ -97,8 +97,7 @@ def main():
                 for _ in range(4)]
         big = torch.randn(M, 4096, device=dev).to(BF)
         between = lambda: ops.swiglu_fwd(big)  # 268 MB read + 134 MB written: evicts L2 / most of the Infinity Cache
-        for v, vn in ((0, 'auto'), (10, 'deep256x256'), (16, 'offs256x256'), (13, 'p2_256x256'), (12, 'deep256x192'), (17, 'offs256x192'), (14, 'p2_256x192'),
-                      (11, 'deep256x128'), (18, 'offs256x128')):
+        for v, vn in ((0, 'auto'), (3, 'plain256x256'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128')):
           fns = [(lambda X=X, W=W, O=O: ops.gemm_nt(X, W, out=O, variant=v)) for X, W, O in sets]
           rec(f'{name} [in-step {vn}]', timeit_instep(fns, a.iters, between), flops=2.0 * m * n * k)
         del sets, big

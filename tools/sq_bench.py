@@ -10,7 +10,7 @@ from plainlm_amd import ops  # noqa: E402
 from tools.kbench import timeit  # noqa: E402
 
 BF = torch.bfloat16
-VARIANTS = ((0, 'auto'), (3, 'big256'), (5, 'stag256'), (7, 'onebar256'), (10, 'deep256'), (9, 'w4'), (-1, 'vendor'))
+VARIANTS = ((0, 'auto'), (3, 'plain256'), (4, 'deep256'), (-1, 'vendor'))
 
 
 def main():

@@ -34,15 +34,17 @@ struct PipeRegs {
 // The first 4 blocks (the two query tiles on the diagonal of the key block) take the masked softmax.  Blocks outside
 // [0, nb) run on whatever finite or not the ring holds and are never consumed (iteration nb only matters for its C stage; P
 // and dS start as zeros and block -1 reads tile 0, so C of block -1 adds zeros).  Q / dO tiles of 64 queries go through a
-// 4-stage LDS ring (a trip of two iterations touches three tiles); a trip ends with this wave's vmcnt(0) + one barrier,
-// which publishes the tile staged at its top and frees the stage the next LDS-DMA overwrites.
+// 6-stage LDS ring: a trip of two iterations touches three tiles, and a tile is staged FOUR trips before its first reader -
+// with one workgroup per CU nothing else hides the ~1 us an LDS-DMA takes under load (staged two trips ahead the kernel
+// waited for every tile: 269 us against 119 us of arithmetic).  A trip ends with a COUNTED vmcnt that only waits for the
+// tile the next trip needs (the two younger tiles stay in flight) and one barrier.
 // =============================================================================================
 template <int ABL>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pipe_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
                                                                     const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                                     uint16_t* __restrict__ dqkv, int T, int nh) {
-  constexpr int QT = 64, NST = 4;
+  constexpr int QT = 64, PD = 4, NST = PD + 2;  // tiles staged PD trips ahead; a trip touches three tiles
   constexpr int TILE = QT * 128;           // 8 KiB
   constexpr int STAGE = 2 * TILE + 1024;   // Q | dO | lse[64], delta[64]
   __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
@@ -84,16 +86,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pipe_kernel(const uint16
   TileDma dma, dmad;
   dma.init(wave, lane, ld);
   dmad.init(wave, lane, dm);
-  auto stage_tile = [&](int u) {  // query tile u of this workgroup into ring slot u % 4 (tiles past the end: nothing)
+  auto stage_tile = [&](int u) {  // query tile u of this workgroup into ring slot u % NST (tiles past the end: nothing)
     if (u >= ntile) return;
     const int qt0 = (jq_lo + u) * QT;
     char* dst = smem + (u % NST) * STAGE;
     dma.issue_full(dst, base + (int64_t)qt0 * ld, wave);
     dmad.issue_full(dst + TILE, dobase + (int64_t)qt0 * dm, wave);
-    if (wave == 0 && lane < 16) {  // 64 floats = 16 lanes x 16 bytes per statistic
-      dma16_asm(lrow + qt0 + lane * 4, dst + 2 * TILE);
-      dma16_asm(drow + qt0 + lane * 4, dst + 2 * TILE + 256);
-    }
+    if (wave < 2 && lane < 16)  // 64 floats = 16 lanes x 16 bytes per statistic: wave 0 brings lse, wave 1 delta
+      dma16_asm((wave == 0 ? lrow : drow) + qt0 + lane * 4, dst + 2 * TILE + wave * 256);
+  };
+  // end of a trip: the tile staged PD - 2 trips ago (needed by the next trip) has landed for this wave; younger ones may fly
+  auto wait_tile = [&](bool counted) {
+    if (ABL == 4) return;
+    if (!counted) attn_wait_vm<0>();
+    else if (wave < 2) attn_wait_vm<(PD - 2) * 5>();  // TileDma: 2 + 2 instructions per tile, + 1 statistic
+    else attn_wait_vm<(PD - 2) * 4>();
   };
   auto tile_of = [&](int bi) { return smem + ((max(bi, 0) >> 1) % NST) * STAGE; };
   bf16x8_t rq[4], rdo[4];          // row fragments of Q / dO (A stage)
@@ -171,9 +178,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pipe_kernel(const uint16
 
   // ---- prologue: tiles 0, 1 land; S / dP and the statistics of block 0 are prepared
   PipeRegs X, Y;
-  stage_tile(0);
-  stage_tile(1);
-  attn_wait_vm<0>();
+#pragma unroll
+  for (int u = 0; u < PD; ++u) stage_tile(u);
+  wait_tile(ntile >= PD);  // tiles 0 and 1
   attn_barrier();
   load_rows(0);
   load_stats(0);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pipe_kernel(const uint16
   }
   // ---- main loop: two blocks (one query tile) per trip, X and Y swap roles
   for (int bi = 0; bi <= nb; bi += 2) {
-    stage_tile((bi >> 1) + 2);  // ring slot of tile (bi >> 1) - 2: every wave finished reading it before the last barrier
+    stage_tile((bi >> 1) + PD);  // ring slot of tile (bi >> 1) - 2: every wave finished reading it before the last barrier
     const bool two = bi + 1 <= nb;  // the last trip only owes the C stage of block nb - 1
     if (bi < 4) {
       iteration(bi, X, Y, std::true_type{});
@@ -198,9 +205,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pipe_kernel(const uint16
       iteration(bi, X, Y, std::false_type{});
       if (two) iteration(bi + 1, Y, X, std::false_type{});
     }
-    attn_wait_vm<0>();
+    wait_tile((bi >> 1) + PD < ntile);
     attn_barrier();
   }
+  attn_wait_vm<0>();
 
   {
     uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
@@ -234,7 +242,9 @@ void plm_launch_attn_bwd_dkdv_pipe(const uint16_t* qkv, const uint16_t* dout, co
                                    const float* rope_sin, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
   static const int abl = getenv("PLM_ATTN_ABL") ? atoi(getenv("PLM_ATTN_ABL")) : 0;
   const dim3 grid((unsigned)((T / 128) * nh * B)), block(256);
-  if (abl == 2)
+  if (abl == 4)
+    hipLaunchKernelGGL(attn_bwd_dkdv_pipe_kernel<4>, grid, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, dqkv, (int)T, (int)nh);
+  else if (abl == 2)
     hipLaunchKernelGGL(attn_bwd_dkdv_pipe_kernel<2>, grid, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, dqkv, (int)T, (int)nh);
   else if (abl == 3)
     hipLaunchKernelGGL(attn_bwd_dkdv_pipe_kernel<3>, grid, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, dqkv, (int)T, (int)nh);

@@ -5,6 +5,8 @@
 //   V  64 independent v_fma_f32                                                        E  32 v_exp_f32
 //   C  32 v_cvt_pk_bf16_f32 + 32 v_fma                                                 L  16 ds_read_b128 + 16 v_fma
 //   X  one wave interleaving: per MFMA, F filler VALU (F = 4 / 6 / 8) - "fillers hidden per MFMA gap"
+//   XL1 / XL2  one wave: 16 MFMAs with a ds_read_b128 behind every / every second one (results consumed a round later)
+//   XG   one wave, the k-step of a 128x128-per-wave GEMM: 16 MFMAs + 8 ds_read_b128 + 4 LDS-DMA (global_load_lds_dwordx4, L2-resident source)
 //   -  idle (the group exits at once)
 // Prints cycles per round for every configuration: T(M,-), T(-,V), T(M,V) ... so that "max" (overlap) vs "sum" (one issue
 // port) can be read off directly.
@@ -16,7 +18,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum Role { IDLE = 0, MFMA = 1, VFMA = 2, VEXP = 3, VCVT = 4, LDS = 5, MIX4 = 6, MIX6 = 7, MIX8 = 8, MIX8E = 9, MFMA8 = 10, MFMA16S = 11, MFMA1 = 12, MFMA2 = 13, MFMA_A = 14 };
+enum Role { IDLE = 0, MFMA = 1, VFMA = 2, VEXP = 3, VCVT = 4, LDS = 5, MIX4 = 6, MIX6 = 7, MIX8 = 8, MIX8E = 9, MFMA8 = 10, MFMA16S = 11, MFMA1 = 12, MFMA2 = 13, MFMA_A = 14, XL1 = 15, XL2 = 16, XG = 17, XGV = 18 };
 
 template <int F, bool EXPS>
 __device__ __forceinline__ void mix_round(f32x16 (&acc)[4], bf16x8 a, bf16x8 b, float (&v)[16]) {
@@ -33,12 +35,12 @@ __device__ __forceinline__ void mix_round(f32x16 (&acc)[4], bf16x8 a, bf16x8 b, 
 }
 
 template <int role0, int role1>
-__global__ __launch_bounds__(512, 2) void k(int iters, long long* cycles, float* sink) {
+__global__ __launch_bounds__(512, 2) void k(int iters, long long* cycles, float* sink, const char* gbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int role = wave < 4 ? role0 : role1;
-  constexpr bool U4 = role0 == MFMA || role1 == MFMA || role0 == MFMA1 || role1 == MFMA1 || role0 == MFMA2 || role1 == MFMA2 || role0 >= MIX4 && role0 <= MIX8E || role1 >= MIX4 && role1 <= MIX8E || role0 == MFMA8 || role1 == MFMA8 || role0 == MFMA_A || role1 == MFMA_A;
+  constexpr bool U4 = role0 == MFMA || role1 == MFMA || role0 == MFMA1 || role1 == MFMA1 || role0 == MFMA2 || role1 == MFMA2 || role0 >= MIX4 && role0 <= MIX8E || role1 >= MIX4 && role1 <= MIX8E || role0 == MFMA8 || role1 == MFMA8 || role0 == MFMA_A || role1 == MFMA_A || role0 >= XL1 || role1 >= XL1;
   constexpr bool U8 = role0 == MFMA8 || role1 == MFMA8;
   constexpr bool U16 = role0 == MFMA16S || role1 == MFMA16S;
   for (int i = threadIdx.x; i < 16384; i += 512) reinterpret_cast<float*>(smem)[i] = (float)i;
@@ -66,6 +68,53 @@ __global__ __launch_bounds__(512, 2) void k(int iters, long long* cycles, float*
         if (i & 4) acc8[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc8[i & 3], 0, 0, 0);
         else acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
       }
+    } else if ((role0 == XL1 || role1 == XL1) && role == XL1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + i * 1024 + it * 64) & 65535));
+        v[i] += q[0];
+      }
+    } else if ((role0 == XL2 || role1 == XL2) && role == XL2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        if (i & 1) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + i * 1024 + it * 64) & 65535));
+          v[i] += q[0];
+        }
+      }
+    } else if ((role0 == XG || role1 == XG) && role == XG) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        if (i & 1) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + i * 1024 + it * 64) & 65535));
+          v[i] += q[0];
+        }
+        if ((i & 3) == 2) {  // LDS-DMA: 1 KiB per wave-instruction into the upper 32 KiB of the LDS block
+          unsigned keep;
+          const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((const __attribute__((address_space(3))) void*)(smem + 65536 + wave * 4096 + (i >> 2) * 1024)));
+          const char* src = gbuf + ((blockIdx.x * 8 + wave) * 4 + (i >> 2)) * 1024 + lane * 16;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if ((role0 == XGV || role1 == XGV) && role == XGV) {  // the same reads + DMA, no MFMAs
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i & 1) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + i * 1024 + it * 64) & 65535));
+          v[i] += q[0];
+        }
+        if ((i & 3) == 2) {
+          unsigned keep;
+          const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((const __attribute__((address_space(3))) void*)(smem + 65536 + wave * 4096 + (i >> 2) * 1024)));
+          const char* src = gbuf + ((blockIdx.x * 8 + wave) * 4 + (i >> 2)) * 1024 + lane * 16;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else if ((role0 == MFMA_A || role1 == MFMA_A) && role == MFMA_A) {  // 4 accumulators held in AGPRs (inline asm: hipcc prefers VGPRs)
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i & 3]) : "v"(a), "v"(b));
@@ -136,13 +185,13 @@ __global__ __launch_bounds__(512, 2) void k(int iters, long long* cycles, float*
 }
 
 template <int R0, int R1>
-void run(const char* n0, const char* n1, long long* cyc, float* sink, hipEvent_t e0, hipEvent_t e1) {
+void run(const char* n0, const char* n1, long long* cyc, float* sink, hipEvent_t e0, hipEvent_t e1, const char* gbuf) {
   const int iters = 2000;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k<R0, R1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   for (int rep = 0; rep < 2; ++rep) {
     hipMemset(cyc, 0, 8 * sizeof(long long));
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<R0, R1>), dim3(256), dim3(512), 100 * 1024, 0, iters, cyc, sink);
+    hipLaunchKernelGGL((k<R0, R1>), dim3(256), dim3(512), 100 * 1024, 0, iters, cyc, sink, gbuf);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -162,7 +211,10 @@ int main() {
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   printf("# cycles per round (s_memtime, wave 0 / wave 4 of workgroup 0); a round = 16 MFMA 32x32x16 (or 32 MFMA 16x16x32) = 512 cycles of matrix pipe at peak;\n# wall = chip-wide ms for 2000 rounds on 256 workgroups\n");
-#define RUN(A, B) run<A, B>(#A, #B, cyc, sink, e0, e1)
+char* gbuf;
+  (void)hipMalloc(&gbuf, 256 * 8 * 4 * 1024);
+  (void)hipMemset(gbuf, 0, 256 * 8 * 4 * 1024);
+#define RUN(A, B) run<A, B>(#A, #B, cyc, sink, e0, e1, gbuf)
   RUN(MFMA1, IDLE); RUN(MFMA2, IDLE); RUN(MFMA, IDLE); RUN(MFMA8, IDLE); RUN(MFMA16S, IDLE);
   RUN(MFMA_A, IDLE); RUN(MFMA_A, MFMA_A); RUN(MFMA_A, VFMA);
   RUN(MFMA1, MFMA1); RUN(MFMA2, MFMA2); RUN(MFMA, MFMA); RUN(MFMA8, MFMA8); RUN(MFMA16S, MFMA16S);
@@ -172,5 +224,6 @@ int main() {
   RUN(LDS, IDLE); RUN(LDS, LDS); RUN(MFMA, LDS);
   RUN(MIX4, IDLE); RUN(MIX6, IDLE); RUN(MIX8, IDLE); RUN(MIX8E, IDLE); RUN(MIX4, MIX4); RUN(MIX8, MIX8); RUN(MIX8E, MIX8E);
   RUN(VFMA, VEXP); RUN(VFMA, LDS);
+  RUN(XL1, IDLE); RUN(XL2, IDLE); RUN(XG, IDLE); RUN(XGV, IDLE); RUN(XL1, XL1); RUN(XL2, XL2); RUN(XG, XG); RUN(XGV, XGV);
   return 0;
 }
