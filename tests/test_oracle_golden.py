@@ -216,3 +216,20 @@ def test_bf16_mode_engine_tracks_the_reference_trajectory(mdl, golden_dir):
   assert (np.abs(lx - en['losses']) / en['losses']).max() <= 2e-6
   rel = np.abs(le - en['losses']) / en['losses']
   assert 1e-7 < rel.max() <= 1e-4, rel  # rounding is on (non-zero) and harmless (<= 1e-4), also after the updates
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='needs the reference checkout (build container only)')
+def test_reference_resumes_hip_checkpoint(golden_dir):
+  """SURVEY section 8f N4, HipEngine -> reference: tests/golden/hip_ckpt_step_2.pth was written on an MI355X by HipEngine
+  (test_engine_checkpoint_has_the_reference_layout); the REFERENCE engine (imported in a child process so that its
+  top-level packages do not shadow ours) resumes from it with engine/engine.py:56-60,86-89 and reproduces, within 1e-4,
+  both HipEngine's own continuation and the continuation the reference got from its own checkpoint."""
+  import subprocess
+  import sys
+  if not os.path.exists(os.path.join(golden_dir, 'hip_ckpt_step_2.pth')):
+    pytest.skip('no HipEngine checkpoint fixture yet')
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+  r = subprocess.run([sys.executable, os.path.join(golden_dir, 'check_hip_ckpt_with_reference.py'), golden_dir], env=env,
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+  assert 'reference engine resumed from the HipEngine checkpoint' in r.stdout
