@@ -78,6 +78,14 @@ int plm_rmsnorm_bwd(const uint16_t* dy, const float* x, const float* w, const fl
                     float* dx, uint16_t* dx_bf16, float* dw_partial, int64_t M, int64_t d, void* stream);
 /* out[j] (+)= sum_r part[r, j]; accumulate != 0 adds into out. */
 int plm_colsum_f32(const float* part, float* out, int64_t rows, int64_t cols, int accumulate, void* stream);
+/* the same reduction for a whole list of partial buffers in ONE launch (all RMSNorm weight gradients of a backward pass:
+ * 25 at the 160M size, each a few microseconds of launch-bound work); every item has the same rows x cols */
+typedef struct plm_colsum_item {
+  const float* part; /* fp32 [rows, cols] */
+  float* out;        /* fp32 [cols] */
+  int accumulate;
+} plm_colsum_item;
+int plm_colsum_f32_multi(const plm_colsum_item* items, int count, int64_t rows, int64_t cols, void* stream);
 
 /* ---- SwiGLU gate (models/components.py:55-56) ---------------------------
  * u bf16[M,2h] = fc1 output, x = u[:, :h], z = u[:, h:]

@@ -30,6 +30,11 @@ class CastItem(C.Structure):
   _fields_ = [('src', _P), ('dst', _P), ('dst_t', _P), ('rows', _I64), ('cols', _I64), ('ld_t', _I64)]
 
 
+class ColsumItem(C.Structure):
+  """struct plm_colsum_item (include/plainlm_hip.h)."""
+  _fields_ = [('part', _P), ('out', _P), ('accumulate', _I)]
+
+
 class TnProblem(C.Structure):
   """struct plm_tn_problem (include/plainlm_hip.h)."""
   _fields_ = [('A', _P), ('lda', _I64), ('B', _P), ('ldb', _I64), ('C', _P), ('ldc', _I64), ('M', _I64), ('N', _I64),
@@ -51,6 +56,7 @@ SIGNATURES = {
   'plm_rmsnorm_bwd_blocks': (_I64, [_I64]),
   'plm_rmsnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
   'plm_colsum_f32': (_I, [_P, _P, _I64, _I64, _I, _P]),
+  'plm_colsum_f32_multi': (_I, [C.POINTER(ColsumItem), _I, _I64, _I64, _P]),
   'plm_swiglu_fwd': (_I, [_P, _P, _I64, _I64, _P]),
   'plm_swiglu_bwd': (_I, [_P, _P, _P, _I64, _I64, _P]),
   'plm_gemm_bf16_nt': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _P]),

@@ -613,6 +613,59 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
 }
 
+#define PLM_COLSUM_MAX 64
+struct ColsumGroup {
+  const float* part[PLM_COLSUM_MAX];
+  float* out[PLM_COLSUM_MAX];
+  unsigned long long accumulate_mask;
+};
+// blockIdx.y = item: the single-item kernel's body on that item's buffers
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumGroup g, int64_t rows, int64_t cols) {
+  __shared__ float red[16][64];
+  const float* __restrict__ part = g.part[blockIdx.y];
+  float* __restrict__ out = g.out[blockIdx.y];
+  const int accumulate = (int)((g.accumulate_mask >> blockIdx.y) & 1ull);
+  const int c = threadIdx.x & 63, gi = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < cols) {
+    int64_t r = gi;
+    for (; r + 48 < rows; r += 64) {
+      s0 += part[r * cols + col];
+      s1 += part[(r + 16) * cols + col];
+      s2 += part[(r + 32) * cols + col];
+      s3 += part[(r + 48) * cols + col];
+    }
+    for (; r < rows; r += 16) s0 += part[r * cols + col];
+  }
+  red[gi][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (gi == 0 && col < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][c];
+    out[col] = accumulate ? out[col] + s : s;
+  }
+}
+
+extern "C" int plm_colsum_f32_multi(const plm_colsum_item* items, int count, int64_t rows, int64_t cols, void* stream) {
+  PLM_REQUIRE(items && count >= 1 && rows > 0 && cols > 0, "plm_colsum_f32_multi: bad arguments");
+  for (int first = 0; first < count; first += PLM_COLSUM_MAX) {
+    const int n = count - first < PLM_COLSUM_MAX ? count - first : PLM_COLSUM_MAX;
+    ColsumGroup g;
+    g.accumulate_mask = 0ull;
+    for (int i = 0; i < n; ++i) {
+      PLM_REQUIRE(items[first + i].part && items[first + i].out, "plm_colsum_f32_multi: null pointer in item %d", first + i);
+      g.part[i] = items[first + i].part;
+      g.out[i] = items[first + i].out;
+      if (items[first + i].accumulate) g.accumulate_mask |= 1ull << i;
+    }
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)plm_cdiv(cols, 64), (unsigned)n), dim3(1024), 0, (hipStream_t)stream, g, rows, cols);
+    PLM_CHECK_LAUNCH("plm_colsum_f32_multi");
+  }
+  return PLM_OK;
+}
+
 extern "C" int plm_colsum_f32(const float* part, float* out, int64_t rows, int64_t cols, int accumulate, void* stream) {
   PLM_REQUIRE(part && out && rows > 0 && cols > 0, "plm_colsum_f32: bad arguments");
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)plm_cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, part, out, rows, cols, accumulate);

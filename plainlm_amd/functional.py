@@ -29,6 +29,9 @@ class GradSink:
     # rounds of work items on all CUs and one reduce instead of four (measured -8 % on the block's dW time).
     self.dw_group = 4
     self.dw_queue = []
+    # RMSNorm weight gradients: the backward kernel leaves per-block partial sums; their column sums (25 launch-bound
+    # kernels at the 160M size) are queued and run as ONE launch when backward reaches the embedding (flush_dw)
+    self.norm_queue = []
 
   def begin_window(self):
     self.flush_dw()
@@ -38,9 +41,29 @@ class GradSink:
     """Queue dW(p) (+)= dy^T x; runs when the group is full or at flush_dw()."""
     self.dw_queue.append((dy, x, p, not self.first_write(p)))
     if len(self.dw_queue) >= max(1, self.dw_group):
-      self.flush_dw()
+      self._flush_linear_dw()
+
+  def defer_norm_dw(self, part, p):
+    self.norm_queue.append((part, p, not self.first_write(p)))
+
+  def flush_norms(self):
+    q, self.norm_queue = self.norm_queue, []
+    if not q:
+      return
+    by_shape = {}
+    for part, p, acc in q:
+      by_shape.setdefault(tuple(part.shape), []).append((part, p.main_grad, acc))
+    for items in by_shape.values():
+      ops.colsum_multi(items)
+    for _, p, _ in q:
+      self.ready(p)
 
   def flush_dw(self):
+    """Everything still queued (end of backward: called when the embedding's gradient is due, and by the optimizer)."""
+    self._flush_linear_dw()
+    self.flush_norms()
+
+  def _flush_linear_dw(self):
     q, self.dw_queue = self.dw_queue, []
     if not q:
       return
@@ -146,9 +169,8 @@ def _norm_dw(norm, dy, x, w, rstd, gin, want_bf16):
   """Shared backward of the two norm Functions; returns (dx, dx_bf16, dw_for_autograd)."""
   sink, p = norm.sink, norm.weight
   if sink is not None and sink.active_for(p):
-    dx, dxb, _ = ops.rmsnorm_bwd(dy, x, w, rstd, gin=gin, want_bf16=want_bf16, dw_out=p.main_grad,
-                                 dw_accumulate=not sink.first_write(p))
-    sink.ready(p)
+    dx, dxb, part = ops.rmsnorm_bwd(dy, x, w, rstd, gin=gin, want_bf16=want_bf16, defer_dw=True)
+    sink.defer_norm_dw(part, p)
     return dx, dxb, None
   return ops.rmsnorm_bwd(dy, x, w, rstd, gin=gin, want_bf16=want_bf16)
 

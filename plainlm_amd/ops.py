@@ -157,8 +157,10 @@ def rmsnorm_fwd(x, w, eps, branch=None, write_xout=False):
   return xout, y, rstd
 
 
-def rmsnorm_bwd(dy, x, w, rstd, gin=None, want_bf16=False, dw_out=None, dw_accumulate=False):
-  """returns (dx fp32, dx_bf16 or None, dw fp32[d]).  dx = gin + d(rmsnorm)."""
+def rmsnorm_bwd(dy, x, w, rstd, gin=None, want_bf16=False, dw_out=None, dw_accumulate=False, defer_dw=False):
+  """returns (dx fp32, dx_bf16 or None, dw fp32[d]).  dx = gin + d(rmsnorm).
+  defer_dw: skip the column sum and return the [nblk, d] per-block partials in place of dw (the caller reduces a whole
+  backward pass's norms with ONE colsum_multi launch)."""
   _need(dy, BF16, 'rmsnorm_bwd.dy', 2)
   _need(x, F32, 'rmsnorm_bwd.x', 2)
   M, d = x.shape
@@ -171,11 +173,28 @@ def rmsnorm_bwd(dy, x, w, rstd, gin=None, want_bf16=False, dw_out=None, dw_accum
   part = torch.empty((nblk, d), dtype=F32, device=x.device)
   _lib.check(lib.plm_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(gin), _p(dx), _p(dxb), _p(part), M, d, _stream()),
              'plm_rmsnorm_bwd')
+  if defer_dw:
+    return dx, dxb, part
   if dw_out is None:
     dw_out = torch.empty((d,), dtype=F32, device=x.device)
     dw_accumulate = False
   _lib.check(lib.plm_colsum_f32(_p(part), _p(dw_out), nblk, d, int(bool(dw_accumulate)), _stream()), 'plm_colsum_f32')
   return dx, dxb, dw_out
+
+
+def colsum_multi(items):
+  """[(part fp32 [rows, d], out fp32 [d], accumulate)] with one common rows x d: out (+)= column sums, ONE launch."""
+  if not items:
+    return
+  rows, d = items[0][0].shape
+  arr = (_lib.ColsumItem * len(items))()
+  for i, (part, out, acc) in enumerate(items):
+    _need(part, F32, 'colsum_multi.part', 2)
+    _need(out, F32, 'colsum_multi.out')
+    if tuple(part.shape) != (rows, d) or out.numel() != d:
+      raise ValueError('colsum_multi: every item needs the same [rows, d] partials and a [d] output')
+    arr[i] = _lib.ColsumItem(part.data_ptr(), out.data_ptr(), int(bool(acc)))
+  _lib.check(_lib.load().plm_colsum_f32_multi(arr, len(items), rows, d, _stream()), 'plm_colsum_f32_multi')
 
 
 # ---- swiglu -----------------------------------------------------------------------

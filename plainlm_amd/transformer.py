@@ -245,18 +245,23 @@ class Transformer(nn.Module):
 
   # ---- flat gradient buffer (our engine / DDP path) ----------------------------
   def enable_main_grad(self):
-    """Allocate one flat fp32 gradient buffer; every parameter gets a ``main_grad`` view into it
-    (in ``parameters()`` order) and the backward kernels write there directly."""
+    """Allocate one flat fp32 gradient buffer; every parameter gets a ``main_grad`` view into it and the backward kernels
+    write there directly.  Placement: the RMSNorm weights first, then everything else in ``parameters()`` order -
+    [norms | embed_tokens | layer 0 ... | lm_head].  ddp.plan_buckets walks the buffer from its end (= the order gradients
+    become ready): lm_head goes first, the layers follow, and the norm weights - whose column sums run as one launch when
+    backward reaches the embedding (GradSink.flush_norms) - share the LAST bucket with embed_tokens.  FlatAdamW uses the
+    same placement (zero-weight-decay group first)."""
     params = list(self.parameters())
     dev = params[0].device
     total = sum(p.numel() for p in params)
     self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-    self._grad_spans = []
-    off = 0
-    for p in params:
+    norm_ids = {id(m.weight) for m in self.modules() if isinstance(m, RMSNorm)}
+    spans, off = {}, 0
+    for p in sorted(params, key=lambda q: id(q) not in norm_ids):  # stable: norms first, otherwise parameters() order
       p.main_grad = self._flat_grad[off:off + p.numel()].view(p.shape)
-      self._grad_spans.append((off, p.numel()))
+      spans[id(p)] = (off, p.numel())
       off += p.numel()
+    self._grad_spans = [spans[id(p)] for p in params]  # parameters() order, as ddp.GradReducer expects
     self.sink.enabled = True
     return self._flat_grad
 

@@ -163,6 +163,23 @@ def test_rmsnorm_golden(ops, golden_dir):
 # --------------------------------------------------------------------------------------
 # SwiGLU
 # --------------------------------------------------------------------------------------
+def test_colsum_multi(ops):
+  """One launch for the column sums of a list of [rows, d] partial buffers (the RMSNorm weight gradients of a backward
+  pass) vs fp64 sums; accumulate adds into the existing output."""
+  g = torch.Generator().manual_seed(9)
+  rows, d = 1024, 768
+  parts = [torch.randn(rows, d, generator=g).cuda() for _ in range(27)]
+  outs = [torch.full((d,), float(i), device='cuda') for i in range(27)]
+  ops.colsum_multi([(p, o, i % 2 == 1) for i, (p, o) in enumerate(zip(parts, outs))])
+  for i, (p, o) in enumerate(zip(parts, outs)):
+    ref = p.double().sum(0) + (float(i) if i % 2 == 1 else 0.0)
+    close(o, ref.float(), 1e-5, f'colsum_multi item {i}')
+  small = torch.randn(5, 64, generator=g).cuda()
+  o1 = torch.empty(64, device='cuda')
+  ops.colsum_multi([(small, o1, False)])
+  close(o1, small.double().sum(0).float(), 1e-6, 'colsum_multi small')
+
+
 @pytest.mark.parametrize('M,h', [(48, 512), (333, 2048), (16, 2816)])
 def test_swiglu_fwd_bwd(ops, M, h):
   g = torch.Generator().manual_seed(h)

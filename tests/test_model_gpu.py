@@ -517,9 +517,7 @@ def test_rccl_reducer_single_rank(P, mdl):
   torch.cuda.synchronize()
   assert n_during_backward == len(red.buckets) == len(fired)  # every bucket launched from inside backward
   assert sum(fired) == m._flat_grad.numel()
-  emb = m.embed_tokens.weight.numel()  # first span: fp32 atomics (order-dependent rounding); everything else is deterministic
-  assert torch.equal(m._flat_grad[emb:], want[emb:])
-  assert relmax(m._flat_grad[:emb], want[:emb]) < 1e-5
+  assert torch.equal(m._flat_grad, want)  # every gradient kernel is deterministic (the embedding backward is sort-based)
   comm.close()
 
 

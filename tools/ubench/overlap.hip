@@ -7,6 +7,8 @@
 //   X  one wave interleaving: per MFMA, F filler VALU (F = 4 / 6 / 8) - "fillers hidden per MFMA gap"
 //   XL1 / XL2  one wave: 16 MFMAs with a ds_read_b128 behind every / every second one (results consumed a round later)
 //   XG   one wave, the k-step of a 128x128-per-wave GEMM: 16 MFMAs + 8 ds_read_b128 + 4 LDS-DMA (global_load_lds_dwordx4, L2-resident source)
+//   XGS  as XG, but the LDS-DMA source is a 64 MB stream that EVERY workgroup walks in the same order (the operand sharing of a
+//        GEMM: one HBM / Infinity-Cache fetch per XCD, L2 hits for its other 31 CUs);  XGP: the same stream, private per workgroup pair of rows
 //   -  idle (the group exits at once)
 // Prints cycles per round for every configuration: T(M,-), T(-,V), T(M,V) ... so that "max" (overlap) vs "sum" (one issue
 // port) can be read off directly.
@@ -18,7 +20,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum Role { IDLE = 0, MFMA = 1, VFMA = 2, VEXP = 3, VCVT = 4, LDS = 5, MIX4 = 6, MIX6 = 7, MIX8 = 8, MIX8E = 9, MFMA8 = 10, MFMA16S = 11, MFMA1 = 12, MFMA2 = 13, MFMA_A = 14, XL1 = 15, XL2 = 16, XG = 17, XGV = 18 };
+enum Role { IDLE = 0, MFMA = 1, VFMA = 2, VEXP = 3, VCVT = 4, LDS = 5, MIX4 = 6, MIX6 = 7, MIX8 = 8, MIX8E = 9, MFMA8 = 10, MFMA16S = 11, MFMA1 = 12, MFMA2 = 13, MFMA_A = 14, XL1 = 15, XL2 = 16, XG = 17, XGV = 18, XGS = 19, XGP = 20, XR = 21 };
 
 template <int F, bool EXPS>
 __device__ __forceinline__ void mix_round(f32x16 (&acc)[4], bf16x8 a, bf16x8 b, float (&v)[16]) {
@@ -100,6 +102,42 @@ __global__ __launch_bounds__(512, 2) void k(int iters, long long* cycles, float*
         }
       }
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if ((role0 == XGS || role1 == XGS || role0 == XGP || role1 == XGP) && (role == XGS || role == XGP)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        if (i & 1) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + i * 1024 + it * 64) & 65535));
+          v[i] += q[0];
+        }
+        if ((i & 3) == 2) {
+          unsigned keep;
+          const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((const __attribute__((address_space(3))) void*)(smem + 65536 + wave * 4096 + (i >> 2) * 1024)));
+          // a [rows][64 k] bf16 panel walk: 8 rows x 128 B per instruction, row stride 1536 B (K = 768), 32 KiB per round and workgroup
+          const long pos = ((long)it * 8 + wave) * 4 + (i >> 2);
+          const long wgoff = role == XGP ? (long)(blockIdx.x & 31) * (2l << 20) : 0;
+          const char* src = gbuf + (wgoff + (pos * 8 + (lane >> 3)) * 1536 + (lane & 7) * 16) % (60l << 20);
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if ((role0 == XR || role1 == XR) && role == XR) {  // the ratio of the shipped 8-wave GEMM: 12 reads + 4 DMA per 16 MFMAs, shared stream
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        if ((i & 3) != 3) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(smem + ((lane * 16 + i * 1024 + it * 64) & 65535));
+          v[i] += q[0];
+        }
+        if ((i & 3) == 2) {
+          unsigned keep;
+          const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((const __attribute__((address_space(3))) void*)(smem + 65536 + wave * 4096 + (i >> 2) * 1024)));
+          const long pos = ((long)it * 8 + wave) * 4 + (i >> 2);
+          const char* src = gbuf + ((pos * 8 + (lane >> 3)) * 1536 + (lane & 7) * 16) % (60l << 20);
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else if ((role0 == XGV || role1 == XGV) && role == XGV) {  // the same reads + DMA, no MFMAs
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -212,8 +250,8 @@ int main() {
   (void)hipEventCreate(&e1);
   printf("# cycles per round (s_memtime, wave 0 / wave 4 of workgroup 0); a round = 16 MFMA 32x32x16 (or 32 MFMA 16x16x32) = 512 cycles of matrix pipe at peak;\n# wall = chip-wide ms for 2000 rounds on 256 workgroups\n");
 char* gbuf;
-  (void)hipMalloc(&gbuf, 256 * 8 * 4 * 1024);
-  (void)hipMemset(gbuf, 0, 256 * 8 * 4 * 1024);
+  (void)hipMalloc(&gbuf, 64l << 20);
+  (void)hipMemset(gbuf, 0, 64l << 20);
 #define RUN(A, B) run<A, B>(#A, #B, cyc, sink, e0, e1, gbuf)
   RUN(MFMA1, IDLE); RUN(MFMA2, IDLE); RUN(MFMA, IDLE); RUN(MFMA8, IDLE); RUN(MFMA16S, IDLE);
   RUN(MFMA_A, IDLE); RUN(MFMA_A, MFMA_A); RUN(MFMA_A, VFMA);
@@ -225,5 +263,6 @@ char* gbuf;
   RUN(MIX4, IDLE); RUN(MIX6, IDLE); RUN(MIX8, IDLE); RUN(MIX8E, IDLE); RUN(MIX4, MIX4); RUN(MIX8, MIX8); RUN(MIX8E, MIX8E);
   RUN(VFMA, VEXP); RUN(VFMA, LDS);
   RUN(XL1, IDLE); RUN(XL2, IDLE); RUN(XG, IDLE); RUN(XGV, IDLE); RUN(XL1, XL1); RUN(XL2, XL2); RUN(XG, XG); RUN(XGV, XGV);
+  RUN(XGS, IDLE); RUN(XGS, XGS); RUN(XGP, XGP); RUN(XR, IDLE); RUN(XR, XR);
   return 0;
 }
