@@ -208,6 +208,38 @@ NT_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1000, 2304, 768),
              (1, 8, 8), (4096, 768, 2048), (300, 768, 50304), (130, 136, 192)]
 
 
+def test_gemm_families_vs_cpu_matmul(ops):
+  """One shape per kernel family against an fp32 matmul computed on the HOST (the other GEMM tests take their reference
+  from the same device's fp32 matmul): persistent NT (the three tile shapes of the automatic policy), the hybrid
+  whole-K + stream-K NT launch, 128x128 NT, persistent TN (whole-K and split-K items), the grouped TN launch."""
+  g = torch.Generator().manual_seed(41)
+  def pair(m, k, n, tn=False):
+    A = bf(torch.randn((k, m) if tn else (m, k), generator=g))
+    B = bf(torch.randn((k, n) if tn else (n, k), generator=g))
+    ref = (A.float().t() @ B.float()) if tn else (A.float() @ B.float().t())
+    return A, B, ref
+  for M, N, K in ((2048, 2304, 768), (2048, 768, 768), (4096, 4096, 256), (200, 136, 72)):
+    A, B, ref = pair(M, K, N)
+    close(ops.gemm_nt(A.cuda(), B.cuda()).float().cpu(), ref, 6e-3, f'gemm_nt {M}x{N}x{K} vs host')
+  A, B, ref = pair(32768, 8192, 768)  # hybrid plan: 384 tiles on 256 CUs
+  assert _lib_ws(32768, 768, 8192) > 0
+  close(ops.gemm_nt(A.cuda(), B.cuda()).float().cpu(), ref, 6e-3, 'gemm_nt hybrid vs host')
+  for M, N, K in ((2304, 768, 4096), (768, 768, 8192), (264, 136, 200)):
+    A, B, ref = pair(M, K, N, tn=True)
+    close(ops.gemm_tn(A.cuda(), B.cuda()).cpu(), ref, 2e-5 * math.sqrt(K) + 1e-6, f'gemm_tn {M}x{N}x{K} vs host')
+  Kc = 4096
+  probs = [pair(m, Kc, n, tn=True) for m, n in ((2304, 768), (768, 768), (4096, 768), (768, 2048))]
+  outs = [torch.zeros(r.shape, device='cuda') for _, _, r in probs]
+  assert ops.gemm_tn_grouped([(a.cuda(), b.cuda(), o, False, None) for (a, b, _), o in zip(probs, outs)])
+  for (_, _, r), o in zip(probs, outs):
+    close(o.cpu(), r, 2e-5 * math.sqrt(Kc), 'gemm_tn_grouped vs host')
+
+
+def _lib_ws(M, N, K):
+  from plainlm_amd import _lib
+  return _lib.load().plm_gemm_nt_workspace_bytes(M, N, K)
+
+
 @pytest.mark.parametrize('M,N,K', NT_SHAPES)
 def test_gemm_nt(ops, M, N, K):
   g = torch.Generator().manual_seed(M + N + K)
