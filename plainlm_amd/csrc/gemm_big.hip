@@ -97,6 +97,11 @@ struct HybridArgs {
 // half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups
 // (80 KiB for 256x256) are in flight behind every counted wait instead of two.  Measured (profiles/r01_kbench_run19*):
 // global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deeper queue lets them overlap.
+// MFMA shape: v_mfma_f32_16x16x32_bf16 (16-row fragments, two K-steps of 32 per K-tile; lane = row l15 of a 16-row block, K-chunk
+// q = lane >> 4).  The GEMMs of the step run at the board's power limit, not at an issue limit (tools/power_probe.py: the same launch
+// on zero operands is 17-41 % faster); per flop this shape moves a quarter of the accumulator registers of 32x32x16 per instruction
+// and measured 7-12 % more flops under the cap (tools/ubench/mfma_power.hip), +4-10 % on every NT shape of the step, for the same
+// ds_read_b128 count and bytes and twice the MFMA instructions.
 template <int BM, int BN, int WM, int WN, bool STAG, bool HYB = false, bool DEEP = false, bool OFFS = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #ifndef PLM_NO_PRIO_HALF
   if (!STAG && wave >= 4) __builtin_amdgcn_s_setprio(1);  // (the staggered schedule flips priorities per section itself)
 #endif
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int l15 = lane & 15, q = lane >> 4;  // fragment coordinates: row inside a 16-row block, K-chunk
   // HYB = false instantiations keep the plain schedule free of the stream-K bookkeeping
   const int rfull = HYB ? hyb.rfull : tiles_m;
   const int n_full = rfull * tiles_n;
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       big_dma16(reinterpret_cast<const char*>(s_bk) + ob[h][i], dst + (i * 8 + wave) * 1024);
     }
   };
-  auto frag = [&](const char* ht, int row, int ks) -> bf16x8_t {
-    return *reinterpret_cast<const bf16x8_t*>(ht + big_swz(row, ks * 2 + hi));
+  auto frag16 = [&](const char* ht, int row, int ks) -> bf16x8_t {  // row = 16-row block base + l15; ks = K-step of 32
+    return *reinterpret_cast<const bf16x8_t*>(ht + big_swz(row, ks * 4 + q));
   };
 
   const int first = xcd_remap(blockIdx.x, gridDim.x);
@@ -315,13 +320,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     int m0 = 0, n0 = 0, kbeg = 0, kend = K, split = -1;
     if (HYB) take(cc, m0, n0, kbeg, kend, split);
     const int nk = HYB ? (kend - kbeg) / 64 : nkt;
-    f32x16_t acc[2 * AF][NBF];
+    f32x4_t acc4[4 * AF][2 * NBF];  // [16-row block of the wave's 2 * AH rows][16-column block of its TN columns]
 #pragma unroll
-    for (int i = 0; i < 2 * AF; ++i)
+    for (int i = 0; i < 4 * AF; ++i)
 #pragma unroll
-      for (int j = 0; j < NBF; ++j)
+      for (int j = 0; j < 2 * NBF; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
       // workgroup-uniform: the staging cursor still points at a K-tile.  DEEP: constant - when a workgroup runs out of K-tiles it
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       bool more = DEEP || s_item < ntiles;
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
-      bf16x8_t a[AF][4], b0[BF0][4], b1[4];
+      bf16x8_t a6[2 * AF][2], b06[2 * BF0][2], b16[2][2];  // fragments: [16-row block][K-step of 32]
       // end of a phase's READ section / MFMA section
       auto end_read = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
@@ -364,11 +369,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         issue_a(0, nxt, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < BF0; ++j) b0[j][ks] = frag(cur + OFF_B0, (wn * BF0 + j) * 32 + l31, ks);
+        for (int j = 0; j < 2 * BF0; ++j) b06[j][ks] = frag16(cur + OFF_B0, wn * BF0 * 32 + j * 16 + l15, ks);
 #pragma unroll
-        for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A0, wm * AH + f * 32 + l31, ks);
+        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = frag16(cur + OFF_A0, wm * AH + f * 16 + l15, ks);
       }
       if (STAG) {
         if (more) issue_a(0, nxt, s_k);  // behind the reads: their latency hides the DMA issue
@@ -376,11 +381,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       }
       if (OFFS && grp1) end_read(integral_constant<int, D_P1>{});
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f)
+        for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
-          for (int j = 0; j < BF0; ++j) acc[f][j] = mfma32(b0[j][ks], a[f][ks], acc[f][j]);
+          for (int j = 0; j < 2 * BF0; ++j) acc4[f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[f][j]);
       if (STAG) end_mfma(); else if (!grp1) end_read(integral_constant<int, DEEP ? D_P1 : W_P1>{});
 
       // ---- phase 2: quadrant (A0, B1); stage B0 (DEEP: A0 two K-tiles ahead, into the slot phase 1 just read)
@@ -390,16 +395,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         issue_b(0, nxt, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(cur + OFF_B1, wn * 32 + l31, ks);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b16[c][ks] = frag16(cur + OFF_B1, wn * 32 + c * 16 + l15, ks);
       if (STAG) {
         if (more) issue_b(0, nxt, s_k);
         end_read(integral_constant<int, W_P2>{});
       }
       if (OFFS && grp1) end_read(integral_constant<int, D_P2>{});
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[f][BF0] = mfma32(b1[ks], a[f][ks], acc[f][BF0]);
+        for (int f = 0; f < 2 * AF; ++f)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc4[f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[f][2 * BF0 + c]);
       if (STAG) end_mfma(); else if (!grp1) end_read(integral_constant<int, DEEP ? D_P2 : W_P2>{});
 
       // ---- phase 3: quadrant (A1, B1); stage B1 (DEEP: B0).  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
@@ -409,9 +418,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         issue_b(1, nxt, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) a[f][ks] = frag(cur + OFF_A1, wm * AH + f * 32 + l31, ks);
+        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = frag16(cur + OFF_A1, wm * AH + f * 16 + l15, ks);
       if (STAG) {
         if (more) issue_b(1, nxt, s_k);
         asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -419,9 +428,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       }
       if (OFFS && grp1) end_read(integral_constant<int, D_P4 - B1_DMA>{});  // B1'' is only issued in phase 4
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[AF + f][BF0] = mfma32(b1[ks], a[f][ks], acc[AF + f][BF0]);
+        for (int f = 0; f < 2 * AF; ++f)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[2 * AF + f][2 * BF0 + c]);
       if (STAG) end_mfma();
 
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1 (DEEP: B1)
@@ -435,11 +446,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         end_read(integral_constant<int, W_P4>{});
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f)
+        for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
-          for (int j = 0; j < BF0; ++j) acc[AF + f][j] = mfma32(b0[j][ks], a[f][ks], acc[AF + f][j]);
+          for (int j = 0; j < 2 * BF0; ++j) acc4[2 * AF + f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[2 * AF + f][j]);
       if (STAG) {
         end_mfma();
       } else {
@@ -457,18 +468,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       const int mrem = M - rfull * BM;
       float* slab = hyb.slabs + ((int64_t)split * mrem - (int64_t)rfull * BM) * N;
 #pragma unroll
-      for (int mf = 0; mf < 2 * AF; ++mf) {
-        const int gm = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32 + l31;
+      for (int f = 0; f < 4 * AF; ++f) {  // 16-row block f of the wave: A half f / (2 AF), block f % (2 AF) inside it
+        const int gm = m0 + wm * TM + (f / (2 * AF)) * AH + (f % (2 * AF)) * 16 + l15;
         if (gm >= M) continue;
 #pragma unroll
-        for (int bh = 0; bh < NBF; ++bh) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int gn = n0 + wn * TN + bh * 32 + 8 * g + 4 * hi;
-            if (gn >= N) continue;
-            const f32x4_t v = {acc[mf][bh][4 * g + 0], acc[mf][bh][4 * g + 1], acc[mf][bh][4 * g + 2], acc[mf][bh][4 * g + 3]};
-            *reinterpret_cast<f32x4_t*>(slab + (int64_t)gm * N + gn) = v;
-          }
+        for (int j = 0; j < 2 * NBF; ++j) {
+          const int gn = n0 + wn * TN + j * 16 + 4 * q;
+          if (gn >= N) continue;
+          *reinterpret_cast<f32x4_t*>(slab + (int64_t)gm * N + gn) = acc4[f][j];
         }
       }
       continue;
@@ -486,13 +493,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           if (bq >= nb) continue;
           const int bh = p0 + bq;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            bf16x4_t o;
+          for (int sr = 0; sr < 2; ++sr)  // 16-row half of the 32-row piece
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mf][bh][4 * g + e] * alpha);
-            const int c = bq * 4 + g;  // 16-byte chunk of the pass's row; this lane fills half `hi` of it
-            *reinterpret_cast<bf16x4_t*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4) + hi * 8) = o;
-          }
+            for (int sc = 0; sc < 2; ++sc) {  // 16-column half of the 32-column block: this lane holds columns 4 q .. 4 q + 3 of it
+              bf16x4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc4[(mf / AF) * 2 * AF + (mf % AF) * 2 + sr][bh * 2 + sc][e] * alpha);
+              const int row = sr * 16 + l15, c = bq * 4 + sc * 2 + (q >> 1);
+              *reinterpret_cast<bf16x4_t*>(epi + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = o;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -546,6 +555,10 @@ struct TnGroup {
                // split's A / B panels in L2, which the tile-major stream cannot offer); L is then the split length in K-tiles
 };
 
+// v_mfma_f32_16x16x32_bf16 (see gemm_nt_big_kernel): a lane group of 16 reads K-chunk q = lane >> 4 of a 16-column block, so the
+// four groups of one transpose read touch k-rows 8 apart - the pair rotation takes bit 3 of the k-row as well as its low two bits.
+__device__ __forceinline__ int tn_rot(int k) { return 2 * (k & 3) + ((k >> 3) & 1); }
+
 template <bool DEEP, bool GROUPED = false, bool OFFS = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
@@ -567,7 +580,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #ifndef PLM_NO_PRIO_HALF_TN
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (see gemm_nt_big_kernel)
 #endif
-  const int l31 = lane & 31, hi = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
+  const int t16 = lane & 15;
+  const int q = lane >> 4;  // K-chunk of the lane group
   const int n_full = rfull * tiles_n;
   const int n_rem = tiles_m * tiles_n - n_full;
   const int nkt = K / 64;
@@ -649,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 8 + wave) * 4 + (lane >> 4);
       const int pp = (lane & 15) >> 1, half16 = lane & 1;
-      const int cb = (pp - 2 * (row & 3)) & 7;   // logical 32-byte pair held at physical position pp
+      const int cb = (pp - tn_rot(row)) & 7;     // logical 32-byte pair held at physical position pp
       const int c = cb * 16 + half16 * 8;        // logical column inside the half-tile (0..127)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -665,10 +679,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < 2; ++i) dma16_saddr_asm(kb, off[i], dst + (i * 8 + wave) * 1024);
   };
-  // operand fragment: 32 logical columns starting at c0 of a half-tile, k-step ks, by two transpose reads
-  auto tr_frag = [&](const char* ht, int c0, int ks) -> bf16x8_t {
-    const int row = ks * 16 + hi * 8 + (t16 >> 2);
-    const char* p = ht + row * 256 + ((((c0 >> 4) + ib) + 2 * (row & 3)) & 7) * 32 + (t16 & 3) * 8;
+  // operand fragment: 16 logical columns starting at c0 of a half-tile, K-step of 32 `ks` (lane group q holds k = ks*32 + q*8 .. +7),
+  // by two transpose reads
+  auto tr_frag16 = [&](const char* ht, int c0, int ks) -> bf16x8_t {
+    const int row = ks * 32 + q * 8 + (t16 >> 2);
+    const char* p = ht + row * 256 + (((c0 >> 4) + tn_rot(row)) & 7) * 32 + (t16 & 3) * 8;
     return join_tr(lds_read_tr16(p), lds_read_tr16(p + 4 * 256));
   };
 
@@ -725,13 +740,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     coords(item, i0, j0, kbeg, kend, split);
     if (GROUPED && kend <= kbeg) continue;  // this run has no piece in that tile
     const int e_tile = c_tile;
-    f32x16_t acc[2 * AF][2];
+    f32x4_t acc4[4 * AF][4];  // [16-row block of the wave's 128 rows][16-column block of its 64 columns]
 #pragma unroll
-    for (int i = 0; i < 2 * AF; ++i)
+    for (int i = 0; i < 4 * AF; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg) / 64;
     for (int kt = 0; kt < nk; ++kt) {
@@ -739,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       char* sst = smem + s_st * STAGE;
       const char* cur = smem + st * STAGE;
       char* nxt = smem + (st ^ 1) * STAGE;
-      bf16x8_t a[AF][4], b0[4], b1[4];
+      bf16x8_t a6[2 * AF][2], b06[2][2], b16[2][2];  // fragments: [16-column block][K-step of 32]
 
       if (DEEP) {
         if (more) {
@@ -752,10 +767,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
         issue(s_ap, pa[0], s_lda, nxt + OFF_A0, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        b0[ks] = tr_frag(cur + OFF_B0, wn * 32, ks);
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int f = 0; f < AF; ++f) a[f][ks] = tr_frag(cur + OFF_A0, wm * AH + f * 32, ks);
+        for (int c = 0; c < 2; ++c) b06[c][ks] = tr_frag16(cur + OFF_B0, wn * 32 + c * 16, ks);
+#pragma unroll
+        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = tr_frag16(cur + OFF_A0, wm * AH + f * 16, ks);
       }
       auto sync = [&](auto wtag) {
         if (more) wait_vm<decltype(wtag)::value>(); else wait_vm<0>();
@@ -764,43 +780,53 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       using WAll = std::integral_constant<int, W_ALL>;
       if (grp1) sync(WAll{});  // OFFS: the second wave group's barrier sits between the reads and the MFMAs (see gemm_nt_big_kernel)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[f][0] = mfma32(a[f][ks], b0[ks], acc[f][0]);
+        for (int f = 0; f < 2 * AF; ++f)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc4[f][c] = mfma16(a6[f][ks], b06[c][ks], acc4[f][c]);
       if (!grp1) sync(WAll{});
 
       if (more) {
         if (DEEP) issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k); else issue(s_bp, pb[0], s_ldb, nxt + OFF_B0, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(cur + OFF_B1, wn * 32, ks);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b16[c][ks] = tr_frag16(cur + OFF_B1, wn * 32 + c * 16, ks);
       if (grp1) sync(WAll{});
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[f][1] = mfma32(a[f][ks], b1[ks], acc[f][1]);
+        for (int f = 0; f < 2 * AF; ++f)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc4[f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[f][2 + c]);
       if (!grp1) sync(WAll{});
 
       if (more) {
         if (DEEP) issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k); else issue(s_bp, pb[1], s_ldb, nxt + OFF_B1, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) a[f][ks] = tr_frag(cur + OFF_A1, wm * AH + f * 32, ks);
+        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = tr_frag16(cur + OFF_A1, wm * AH + f * 16, ks);
       if (grp1) sync(std::integral_constant<int, W_ALL - 2>{});  // the fourth DMA group of this K-tile is only issued in phase 4
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[AF + f][1] = mfma32(a[f][ks], b1[ks], acc[AF + f][1]);
+        for (int f = 0; f < 2 * AF; ++f)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[2 * AF + f][2 + c]);
 
       if (more) {
         if (DEEP) issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k); else issue(s_ap, pa[1], s_lda, nxt + OFF_A1, s_k);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < AF; ++f) acc[AF + f][0] = mfma32(a[f][ks], b0[ks], acc[AF + f][0]);
+        for (int f = 0; f < 2 * AF; ++f)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc4[2 * AF + f][c] = mfma16(a6[f][ks], b06[c][ks], acc4[2 * AF + f][c]);
       if (more && !DEEP) advance_staged();
       if (!grp1) {
         if (more) wait_vm<W_ALL>(); else wait_vm<0>();
@@ -809,20 +835,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       st ^= 1;
     }
 
-    // epilogue: D[i][j], lane owns column j = l31, 16 rows per accumulator; 128-byte row segments per half-wave
+    // epilogue: D block (f, j) of 16x16: lane owns column l15 = lane & 15 and rows 4 q .. 4 q + 3; 64-byte row segments per lane group
     if (GROUPED) {  // raw accumulators into this piece's dense 256x256 block (edge rows / columns hold clamped duplicates: ignored)
       float* blk = slabs + ((int64_t)split * grp.tile_base[grp.count] + e_tile) * (BM * BN);
       // one lane offset + a wave-uniform base per store (128 precomputed per-lane addresses spilled to scratch)
-      const unsigned lane_off = (unsigned)(((wm * TM + 4 * hi) * BN + wn * TN + l31) * 4);
+      const unsigned lane_off = (unsigned)(((wm * TM + 4 * q) * BN + wn * TN + (lane & 15)) * 4);
 #pragma unroll
-      for (int mf = 0; mf < 2 * AF; ++mf) {
+      for (int f = 0; f < 4 * AF; ++f) {
 #pragma unroll
-        for (int bh = 0; bh < 2; ++bh) {
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int roff = ((mf / AF) * AH + (mf % AF) * 32 + (r & 3) + 8 * (r >> 2)) * BN + bh * 32;
-            st_f32_saddr(blk + roff, lane_off, acc[mf][bh][r]);
-          }
+          for (int r = 0; r < 4; ++r) st_f32_saddr(blk + (f * 16 + r) * BN + j * 16, lane_off, acc4[f][j][r]);
         }
       }
       continue;
@@ -834,18 +857,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     const float scl = direct ? alpha : 1.f;
     const bool rmw = direct && accumulate;
 #pragma unroll
-    for (int mf = 0; mf < 2 * AF; ++mf) {
-      const int row0 = i0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
+    for (int f = 0; f < 4 * AF; ++f) {
 #pragma unroll
-      for (int bh = 0; bh < 2; ++bh) {
-        const int col = j0 + wn * TN + bh * 32 + l31;
+      for (int j = 0; j < 4; ++j) {
+        const int col = j0 + wn * TN + j * 16 + (lane & 15);
         if (col >= N) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + mfma32_row(r, hi);
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + wm * TM + f * 16 + 4 * q + r;
           if (row >= M) continue;
           float* dst = out + (int64_t)row * ld + col;
-          const float v = acc[mf][bh][r] * scl;
+          const float v = acc4[f][j][r] * scl;
           *dst = rmw ? *dst + v : v;
         }
       }
@@ -889,20 +911,9 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const int slots = persistent_slots();
   const dim3 grid(nitems < slots ? nitems : slots), block(512);
   // deep-prefetch ring + offset wave groups (see gemm_nt_big_kernel): each alone measured equal to the plain ring in the step, together
-  // +0.8 % end to end (run 34); PLM_TN_NO_DEEP / PLM_TN_NO_OFFS bring the other forms back for A/B runs
-  const bool deep = true, offs = true;  // deep-prefetch ring + offset wave groups (+0.8 % end to end, run 34)
-  if (offs && !deep)
-    hipLaunchKernelGGL((gemm_tn_big_kernel<false, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
-                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
-  else if (offs)
-    hipLaunchKernelGGL((gemm_tn_big_kernel<true, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
-                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
-  else if (!deep)
-    hipLaunchKernelGGL((gemm_tn_big_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
-                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
-  else
-    hipLaunchKernelGGL((gemm_tn_big_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
-                       rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
+  // +0.8 % end to end (round 1, run 34)
+  hipLaunchKernelGGL((gemm_tn_big_kernel<true, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
+                     rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
 }
 
 // ---- grouped TN (dW of one transformer block in one stream-K launch) ----------------------------------------------
@@ -1025,16 +1036,8 @@ extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, 
     return PLM_E_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  const bool offs = true, deep = true;
-  if (offs && deep)
-    hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
-                       (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
-  else if (offs)
-    hipLaunchKernelGGL((gemm_tn_big_kernel<false, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
-                       (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
-  else
-    hipLaunchKernelGGL((gemm_tn_big_kernel<false, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
-                       (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
+  hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
+                     (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
   hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3((unsigned)(g.tile_base[count] * 16)), dim3(256), 0, s, (const float*)workspace, g, o,
                      (int)(K / 64));
   PLM_CHECK_LAUNCH("plm_gemm_bf16_tn_grouped");
@@ -1091,6 +1094,12 @@ bool plm_nt_hybrid_plan(int64_t M, int64_t N, int64_t K, NtHybridPlan* p) {
   const int64_t R = plm_cdiv(M, 256), Cn = plm_cdiv(N, 256), tiles = R * Cn, nkt = K / 64;
   if (tiles <= slots) return false;                          // single partial round: nothing to balance
   if (round_efficiency(tiles, slots) >= 0.9) return false;  // plain 256x256 is already well packed
+  // ... or a narrower plain tile is (lm_head dX on the whole chip: 4 x 192 columns = exactly two rounds; in the step that beats the
+  // hybrid's slab traffic by 0.5 % end to end, round 2).  The same per-tile rates as the automatic policy below.
+  const int64_t c192 = plm_cdiv(N, 192), c128 = plm_cdiv(N, 128);
+  const double e192 = round_efficiency(R * c192, slots) * ((double)N / (c192 * 192.0)) * 0.94;
+  const double e128 = round_efficiency(R * c128, slots) * ((double)N / (c128 * 128.0)) * 0.88;
+  if (!mk && (e192 >= 0.9 || e128 >= 0.9)) return false;
   const int64_t rf = ((tiles / slots) * slots) / Cn;        // whole tile rows inside the full rounds
   const int64_t rem = (R - rf) * Cn;
   if (rem <= 0 || rf <= 0) return false;

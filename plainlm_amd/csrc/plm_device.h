@@ -103,6 +103,14 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16:  D[i][j] += sum_k A[i][k] B[k][j]   (same flops per cycle; a quarter of the accumulator registers
+// per instruction - measured 7-12 % more flops at the board's power limit on random operands, tools/ubench/mfma_power.hip)
+//   a: lane l holds A[i = l&15][k-slots (l>>4)*8 + 0..7]
+//   b: lane l holds B[k-slots (l>>4)*8 + 0..7][j = l&15]
+//   d: lane l reg r holds D[i = 4*(l>>4) + r][j = l&15]
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 // row (i) index of accumulator register r for lane-half hi in a 32x32 tile
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -221,9 +221,11 @@ def test_gemm_families_vs_cpu_matmul(ops):
   for M, N, K in ((2048, 2304, 768), (2048, 768, 768), (4096, 4096, 256), (200, 136, 72)):
     A, B, ref = pair(M, K, N)
     close(ops.gemm_nt(A.cuda(), B.cuda()).float().cpu(), ref, 6e-3, f'gemm_nt {M}x{N}x{K} vs host')
-  A, B, ref = pair(32768, 8192, 768)  # hybrid plan: 384 tiles on 256 CUs
-  assert _lib_ws(32768, 768, 8192) > 0
+  # hybrid plan: 640 tiles of 256x256 on 256 CUs (2.5 rounds), and neither 192- nor 128-column tiles pack to >= 0.9
+  A, B, ref = pair(32768, 8192, 1280)
+  assert _lib_ws(32768, 1280, 8192) > 0
   close(ops.gemm_nt(A.cuda(), B.cuda()).float().cpu(), ref, 6e-3, 'gemm_nt hybrid vs host')
+  assert _lib_ws(32768, 768, 8192) == 0  # lm_head dX on the whole chip: 4 x 192 columns = two exact rounds, no hybrid
   for M, N, K in ((2304, 768, 4096), (768, 768, 8192), (264, 136, 200)):
     A, B, ref = pair(M, K, N, tn=True)
     close(ops.gemm_tn(A.cuda(), B.cuda()).cpu(), ref, 2e-5 * math.sqrt(K) + 1e-6, f'gemm_tn {M}x{N}x{K} vs host')
