@@ -171,12 +171,15 @@ class HipEngine(torch.nn.Module):
     self.intra_doc_masking = getattr(cfg, 'intra_doc_masking', False)
     self.device = device
     self._stager = _Stager()
-    # 'Train loss is nan' (engine.py:116-117).  Default 0 = the reference's semantics: the flag of micro-step k is read
-    # (one pinned byte, its own event) before k's backward is enqueued.  nan_check_lag = n > 0 (opt-in) defers the read to the
-    # submission of micro-step k + n so the host never waits inside an accumulation window; the window's LAST micro-step
-    # always drains every outstanding flag before clip + AdamW, so an update computed from a NaN loss is never applied and
-    # no micro-step of a run goes unchecked.
-    self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 0))
+    # 'Train loss is nan' (engine.py:116-117).  The reference reads the loss on the host before it enqueues backward; the host is
+    # close to launch-bound on this path (~250 launches per micro-step), so that read - a wait for the whole forward with an
+    # empty queue behind it - costs 4-8 ms of a 35 ms step (tools/engine_bench.py: 42.2 vs 34.9 ms).  Default nan_check_lag = 1:
+    # the flag of micro-step k (one pinned byte with its own event) is read AFTER k's backward has been enqueued - at the window's
+    # last micro-step, before clip + AdamW, or at the submission of micro-step k + 1 - by which time the forward has long
+    # finished.  The error is raised from the same step() call when k ends a window (always, with accumulation 1) and from the
+    # next call otherwise; an update computed from a NaN loss is never applied, no micro-step goes unchecked (eval() and
+    # check_losses() drain).  nan_check_lag = 0 restores the reference's order exactly; larger values defer further inside a window.
+    self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 1))
     self._unchecked, self._flag_pool = [], []
     if self.dtype != 'bfloat16':
       raise NotImplementedError(f"dtype '{self.dtype}': the gfx950 kernels implement the bfloat16 flow only")
@@ -233,7 +236,7 @@ class HipEngine(torch.nn.Module):
 
     if last:
       self.accumulated_samples = 0
-      self.check_losses()  # lag > 0: no optimizer update from a window that contains a NaN loss
+      self.check_losses()  # no optimizer update from a window that contains a NaN loss
       if hasattr(self.optimizer, 'clip_and_step'):
         self.optimizer.clip_and_step(self.grad_clip or None)  # fused global-norm clip + AdamW on the flat buffers
       else:

@@ -333,15 +333,16 @@ def test_engine_docmask_and_errors(P, mdl):
 
 
 def test_engine_nan_check_and_staging(P, mdl):
-  """engine.py:116-117: a NaN loss raises ValueError BEFORE its backward is enqueued (default, the reference's order).
-  With the opt-in ``nan_check_lag`` the flag is read later - but always before the optimizer step of the window, so a NaN
-  loss never reaches the weights or the AdamW moments, and no micro-step goes unchecked.
+  """engine.py:116-117: a NaN loss raises ValueError('Train loss is nan') and never reaches the weights or the AdamW moments.
+  Default (nan_check_lag = 1): the flag is read after the micro-step's backward has been enqueued - from the same step() call when
+  the micro-step ends an accumulation window (before clip + AdamW), from the next call otherwise.  nan_check_lag = 0 is the
+  reference's order (before backward); larger lags still drain before the optimizer.  No micro-step goes unchecked.
   Also: the pinned staging ring hands over the same tokens as a plain copy."""
   cfg = _engine_cfg(grad_accumulation_steps=1)
   model, _ = P.construct_model(cfg)
   model.load_state_dict(_weights(mdl))
   eng = P.TorchEngine(model, cfg, 'cuda', None, None)
-  assert eng.nan_check_lag == 0
+  assert eng.nan_check_lag == 1
   tok = mdl['tokens']
   from plainlm_amd.engine import _move_to_device, _Stager
   st = _Stager(depth=2)
@@ -351,24 +352,41 @@ def test_engine_nan_check_and_staging(P, mdl):
   ok = eng.step({'input_ids': tok})
   assert torch.isfinite(ok)
   steps_before = eng.optimizer._step_count
-  with torch.no_grad():
-    eng.model.out_norm.weight.fill_(float('nan'))
-  eng.model.invalidate_shadows()
-  with pytest.raises(ValueError, match='Train loss is nan'):
+  before = [p.detach().clone() for p in eng.model.parameters()]
+
+  def poison(e):
+    with torch.no_grad():
+      e.model.out_norm.weight.fill_(float('nan'))
+    e.model.invalidate_shadows()
+
+  poison(eng)
+  with pytest.raises(ValueError, match='Train loss is nan'):  # accumulation 1: raised from the call that produced it
     eng.step({'input_ids': tok})
   assert eng.optimizer._step_count == steps_before and torch.isfinite(eng.optimizer.flat_m).all()
-  # opt-in lag: micro-step 1 of a 2-step window submits a NaN loss and returns; the window's last micro-step drains the
-  # flags before clip + AdamW
+  for (n, p), b in zip(eng.model.named_parameters(), before):
+    if n != 'out_norm.weight':
+      assert torch.equal(p.detach(), b), n  # no update was applied
+  # reference order (opt-in): raised before backward - the gradient buffer is never written
+  model0, _ = P.construct_model(cfg)
+  model0.load_state_dict(_weights(mdl))
+  eng0 = P.TorchEngine(model0, _engine_cfg(grad_accumulation_steps=1, nan_check_lag=0), 'cuda', None, None)
+  eng0.step({'input_ids': tok})
+  poison(eng0)
+  eng0.optimizer.flat_g.fill_(7.0)
+  with pytest.raises(ValueError, match='Train loss is nan'):
+    eng0.step({'input_ids': tok})
+  torch.cuda.synchronize()
+  assert (eng0.optimizer.flat_g == 7.0).all()
+  # accumulation 2, default lag: micro-step 1 submits a NaN loss and returns; micro-step 2 raises before clip + AdamW
   model2, _ = P.construct_model(cfg)
   model2.load_state_dict(_weights(mdl))
-  eng2 = P.TorchEngine(model2, _engine_cfg(grad_accumulation_steps=2, nan_check_lag=2), 'cuda', None, None)
-  with torch.no_grad():
-    eng2.model.out_norm.weight.fill_(float('nan'))
-  eng2.model.invalidate_shadows()
+  eng2 = P.TorchEngine(model2, _engine_cfg(grad_accumulation_steps=2), 'cuda', None, None)
+  poison(eng2)
   eng2.step({'input_ids': tok})  # submitted, not yet checked
   with pytest.raises(ValueError, match='Train loss is nan'):
     eng2.step({'input_ids': tok})
   assert eng2.optimizer._step_count == 0 and torch.isfinite(eng2.optimizer.flat_m).all()
+  # a larger lag inside a long window; an explicit drain (what eval() does) finds the pending flag
   eng3 = P.TorchEngine(model, _engine_cfg(grad_accumulation_steps=4, nan_check_lag=2), 'cuda', None, None)
   eng3.step({'input_ids': tok})
   with pytest.raises(ValueError, match='Train loss is nan'):

@@ -18,12 +18,15 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--accum', type=int, default=1)
+  ap.add_argument('--nan-check-lag', type=int, default=None, help='0 = the reference order (host read before backward); default: the engine default')
   a = ap.parse_args()
   cfg = SimpleNamespace(model='transformer', vocab_size=50280, d_model=768, expand='8/3', n_layers=12, n_heads=12, mlp_class='glu',
                         seq_len=1024, tie_embeddings=False, dtype='bfloat16', optim='adamw', fused_optim=True, lr=3e-4, beta1=0.9,
                         beta2=0.95, weight_decay=0.1, eps=1e-8, scheduler='warmup_cosine', warmup_steps=10, lr_start=0.0, lr_end=1e-5,
                         lr_end_pct=None, steps_budget=1000, grad_accumulation_steps=a.accum, grad_clip=1.0, intra_doc_masking=False,
                         resume=False, seed=100, micro_batch_size=32)
+  if a.nan_check_lag is not None:
+    cfg.nan_check_lag = a.nan_check_lag
   torch.manual_seed(cfg.seed)
   model, _ = P.construct_model(cfg)
   eng = P.TorchEngine(model, cfg, 'cuda', None, None)
@@ -40,7 +43,7 @@ def main():
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   n = a.steps * a.accum
-  print({'engine_ms_per_micro_step': round(1e3 * dt / n, 3), 'tokens_per_s': round(32 * 1024 * n / dt, 1), 'accum': a.accum, 'loss': float(loss)})
+  print({'engine_ms_per_micro_step': round(1e3 * dt / n, 3), 'tokens_per_s': round(32 * 1024 * n / dt, 1), 'accum': a.accum, 'nan_check_lag': eng.nan_check_lag, 'loss': float(loss)})
 
 
 if __name__ == '__main__':
