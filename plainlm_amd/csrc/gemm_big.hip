@@ -537,22 +537,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 // outputs), splits = 1 with no remainder is plain tiling; the hybrid keeps every CU busy for a whole number of rounds.
 // DEEP: see gemm_nt_big_kernel - half-tile slots are refilled two K-tiles ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1
 // of kt+2), five LDS-DMA groups in flight behind every counted wait.
-// GROUPED: up to PLM_TN_GROUP_MAX independent problems with the same contraction length (the dW GEMMs of one transformer
-// block: same token rows, different projections) run as ONE stream-K launch: the K-tiles of all their 256x256 output tiles
-// form one stream cut into `nchunks` equal runs of L K-tiles, one run per workgroup; a run is executed as one piece per
-// tile it touches, every piece writes its raw fp32 accumulators to the dense block ws[(sidx * ntiles + tile)][256][256]
-// (sidx = chunk - first chunk of the tile), tn_grouped_reduce_kernel sums a tile's pieces into C.  Against four
-// separate split-K launches this keeps every CU busy, gives each workgroup a long K run and cuts the slab traffic.
-#define PLM_TN_GROUP_MAX 8
+// GROUPED: up to PLM_TN_GROUP_MAX independent problems with the same contraction length (the dW GEMMs of one or more
+// transformer blocks: same token rows, different projections) run as ONE launch over the union of their 256x256 output tiles,
+// with the same hybrid as above: the first n_full tiles (whole rounds of the persistent grid) take the whole contraction and
+// write (C = / += alpha*acc) themselves, the remaining tiles are split over K into dense fp32 blocks
+// ws[split * n_rem + r][256][256] that tn_grouped_reduce_kernel sums into C.  The more problems a launch carries, the smaller the
+// split remainder: one block (108 tiles) is all remainder (7 pieces per tile), twelve blocks (1296 tiles) leave 16 tiles to split.
+#define PLM_TN_GROUP_MAX 24
+// (kernel arguments: 24 problems x (operands + outputs) = 1.6 KB of kernarg; hipcc 7.0 miscompiles the problem look-up from 32 up)
 struct TnGroup {
   const uint16_t* A[PLM_TN_GROUP_MAX];
   const uint16_t* B[PLM_TN_GROUP_MAX];
-  int64_t lda[PLM_TN_GROUP_MAX], ldb[PLM_TN_GROUP_MAX];
+  int lda[PLM_TN_GROUP_MAX], ldb[PLM_TN_GROUP_MAX];
   int M[PLM_TN_GROUP_MAX], N[PLM_TN_GROUP_MAX], tiles_n[PLM_TN_GROUP_MAX];
   int tile_base[PLM_TN_GROUP_MAX + 1];  // first global tile of each problem; [count] = number of tiles
-  int count, nchunks, L;
-  int splits;  // > 0: uniform split-K instead of stream-K (items = splits x tiles, split-major: the workgroups of an XCD share a
-               // split's A / B panels in L2, which the tile-major stream cannot offer); L is then the split length in K-tiles
+  int count;
+  int n_full;  // tiles 0 .. n_full-1 take the whole contraction and write C directly (whole rounds of the persistent grid)
+  int splits;  // the remaining tiles are cut `splits` ways over K (L K-tiles each): items n_full + split * n_rem + r, split-major so
+  int L;       // that the workgroups of an XCD share a split's A / B panels in L2; pieces go to ws[split * n_rem + r][256][256]
+};
+struct TnGroupOut {
+  float* C[PLM_TN_GROUP_MAX];
+  const float* alpha[PLM_TN_GROUP_MAX];
+  int ldc[PLM_TN_GROUP_MAX];
+  int accumulate[PLM_TN_GROUP_MAX];
 };
 
 // v_mfma_f32_16x16x32_bf16 (see gemm_nt_big_kernel): a lane group of 16 reads K-chunk q = lane >> 4 of a 16-column block, so the
@@ -564,7 +572,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                              int64_t ldc, float* __restrict__ slabs, int M, int N, int K, int kchunk,
                                                              int splits, int rfull, int accumulate,
-                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n, TnGroup grp) {
+                                                             const float* __restrict__ alpha_dev, int tiles_m, int tiles_n, TnGroup grp,
+                                                             TnGroupOut gout) {
   constexpr int BM = 256, BN = 256, WN = 4;
   constexpr int TM = 128, TN = 64, AH = 64, AF = 2;
   constexpr int HT = 64 * 256;  // one half-tile: 64 k-rows x 128 cols bf16
@@ -585,9 +594,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   const int n_full = rfull * tiles_n;
   const int n_rem = tiles_m * tiles_n - n_full;
   const int nkt = K / 64;
-  // GROUPED: item = sub * nchunks + chunk (the launch has exactly nchunks workgroups, so workgroup c meets its own pieces)
-  const int g_sub = GROUPED ? (grp.L + nkt - 2) / nkt + 1 : 0;  // pieces a run can touch
-  const int nitems = GROUPED ? (grp.splits > 0 ? grp.splits * grp.tile_base[grp.count] : g_sub * grp.nchunks) : n_full + n_rem * splits;
+  const int g_ntl = GROUPED ? grp.tile_base[grp.count] : 0, g_nrem = GROUPED ? g_ntl - grp.n_full : 0;
+  const int nitems = GROUPED ? grp.n_full + g_nrem * grp.splits : n_full + n_rem * splits;
   int c_prob = 0, c_tile = 0;  // GROUPED: problem / global tile of the item coords() looked at last
 
   // split = -1: whole-K tile written to C; split >= 0: partial into slab[split]
@@ -595,32 +603,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     int tile;
     if (GROUPED) {
       int t, lo, hi2;
-      if (grp.splits > 0) {
-        const int ntl = grp.tile_base[grp.count];
-        split = item / ntl;
-        t = item - split * ntl;
-        lo = t * nkt + min(nkt, split * grp.L);
-        hi2 = t * nkt + min(nkt, (split + 1) * grp.L);
+      if (item < grp.n_full) {
+        split = -1;
+        t = item;
+        lo = 0;
+        hi2 = nkt;
       } else {
-        const int sub = item / grp.nchunks, c = item - sub * grp.nchunks;
-        const int g0 = c * grp.L, g1 = min(grp.tile_base[grp.count] * nkt, g0 + grp.L);
-        t = g0 / nkt + sub;
-        lo = max(g0, t * nkt);
-        hi2 = min(g1, (t + 1) * nkt);
-        split = c - (t * nkt) / grp.L;
+        const int j = item - grp.n_full;
+        split = j / g_nrem;
+        t = grp.n_full + (j - split * g_nrem);
+        lo = min(nkt, split * grp.L);
+        hi2 = min(nkt, (split + 1) * grp.L);
       }
       kbeg = kend = 0;
       i0 = j0 = 0;
-      if (hi2 <= lo) return;  // the run does not reach this tile
+      if (hi2 <= lo) return;  // an empty split (L does not divide the contraction)
+      // everything here is wave-uniform; saying so keeps the table reads on the scalar unit.  (A VECTOR load of a table entry is
+      // tracked by vmcnt, and hipcc then drains the LDS-DMA ring with s_waitcnt vmcnt(0) at the top of every K-tile: -20 %.)
+      t = __builtin_amdgcn_readfirstlane(t);
       int pidx = 0;
 #pragma unroll
       for (int q = 1; q < PLM_TN_GROUP_MAX; ++q)
         if (q < grp.count && t >= grp.tile_base[q]) pidx = q;
+      pidx = __builtin_amdgcn_readfirstlane(pidx);
       const int local = t - grp.tile_base[pidx];
       i0 = (local / grp.tiles_n[pidx]) * BM;
       j0 = (local % grp.tiles_n[pidx]) * BN;
-      kbeg = (lo - t * nkt) * 64;
-      kend = (hi2 - t * nkt) * 64;
+      kbeg = lo * 64;
+      kend = hi2 * 64;
       c_prob = pidx;
       c_tile = t;
       return;
@@ -654,8 +664,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     const uint16_t* Bp = GROUPED ? grp.B[c_prob] : B;
     const int Mp = GROUPED ? grp.M[c_prob] : M, Np = GROUPED ? grp.N[c_prob] : N;
     if (GROUPED) {
-      s_lda = grp.lda[c_prob];
-      s_ldb = grp.ldb[c_prob];
+      s_lda = (int64_t)grp.lda[c_prob];
+      s_ldb = (int64_t)grp.ldb[c_prob];
     }
     s_ap = Ap;
     s_bp = Bp;
@@ -674,10 +684,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       }
     }
   };
-  auto issue = [&](const uint16_t* base, const unsigned (&off)[2], int64_t ld, char* dst, int k0) {
+  const unsigned smem_u = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));  // LDS byte address of the stage ring
+  auto issue = [&](const uint16_t* base, const unsigned (&off)[2], int64_t ld, unsigned dst, int k0) {
     const uint16_t* kb = base + (int64_t)k0 * ld;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16_saddr_asm(kb, off[i], dst + (i * 8 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) dma16_saddr_u32(kb, off[i], dst + (i * 8 + wave) * 1024);
   };
   // operand fragment: 16 logical columns starting at c0 of a half-tile, K-step of 32 `ks` (lane group q holds k = ks*32 + q*8 .. +7),
   // by two transpose reads
@@ -718,16 +729,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   };
   open_item();
   if (s_item < nitems) {
-    issue(s_ap, pa[0], s_lda, smem + OFF_A0, s_k);
-    issue(s_bp, pb[0], s_ldb, smem + OFF_B0, s_k);
-    issue(s_bp, pb[1], s_ldb, smem + OFF_B1, s_k);
-    issue(s_ap, pa[1], s_lda, smem + OFF_A1, s_k);
+    issue(s_ap, pa[0], s_lda, smem_u + OFF_A0, s_k);
+    issue(s_bp, pb[0], s_ldb, smem_u + OFF_B0, s_k);
+    issue(s_bp, pb[1], s_ldb, smem_u + OFF_B1, s_k);
+    issue(s_ap, pa[1], s_lda, smem_u + OFF_A1, s_k);
     advance_staged();
   }
   if (DEEP && s_item < nitems) {  // plus A0, B0, B1 of the second K-tile
-    issue(s_ap, pa[0], s_lda, smem + STAGE + OFF_A0, s_k);
-    issue(s_bp, pb[0], s_ldb, smem + STAGE + OFF_B0, s_k);
-    issue(s_bp, pb[1], s_ldb, smem + STAGE + OFF_B1, s_k);
+    issue(s_ap, pa[0], s_lda, smem_u + STAGE + OFF_A0, s_k);
+    issue(s_bp, pb[0], s_ldb, smem_u + STAGE + OFF_B0, s_k);
+    issue(s_bp, pb[1], s_ldb, smem_u + STAGE + OFF_B1, s_k);
     wait_vm<W_ALL>();
   } else {
     wait_vm<0>();
@@ -736,10 +747,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 
   int st = 0;
   for (int item = first; item < nitems; item += gridDim.x) {
-    int i0, j0, kbeg, kend, split;
-    coords(item, i0, j0, kbeg, kend, split);
-    if (GROUPED && kend <= kbeg) continue;  // this run has no piece in that tile
-    const int e_tile = c_tile;
+    int nk;
+    {
+      int i0_, j0_, kbeg_, kend_, split_;
+      coords(item, i0_, j0_, kbeg_, kend_, split_);
+      if (GROUPED && kend_ <= kbeg_) continue;  // empty split
+      nk = (kend_ - kbeg_) / 64;
+    }
     f32x4_t acc4[4 * AF][4];  // [16-row block of the wave's 128 rows][16-column block of its 64 columns]
 #pragma unroll
     for (int i = 0; i < 4 * AF; ++i)
@@ -748,12 +762,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
 
-    const int nk = (kend - kbeg) / 64;
     for (int kt = 0; kt < nk; ++kt) {
       bool more = s_item < nitems;  // workgroup-uniform: the staging cursor still points at a K-tile
-      char* sst = smem + s_st * STAGE;
+      unsigned sst = smem_u + s_st * STAGE;
       const char* cur = smem + st * STAGE;
-      char* nxt = smem + (st ^ 1) * STAGE;
+      const unsigned nxt_u = smem_u + (st ^ 1) * STAGE;
       bf16x8_t a6[2 * AF][2], b06[2][2], b16[2][2];  // fragments: [16-column block][K-step of 32]
 
       if (DEEP) {
@@ -761,10 +774,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
           issue(s_ap, pa[1], s_lda, sst + OFF_A1, s_k);
           advance_staged();
           more = s_item < nitems;
-          sst = smem + s_st * STAGE;
+          sst = smem_u + s_st * STAGE;
         }
       } else if (more) {
-        issue(s_ap, pa[0], s_lda, nxt + OFF_A0, s_k);
+        issue(s_ap, pa[0], s_lda, nxt_u + OFF_A0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -788,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       if (!grp1) sync(WAll{});
 
       if (more) {
-        if (DEEP) issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k); else issue(s_bp, pb[0], s_ldb, nxt + OFF_B0, s_k);
+        if (DEEP) issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k); else issue(s_bp, pb[0], s_ldb, nxt_u + OFF_B0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -804,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       if (!grp1) sync(WAll{});
 
       if (more) {
-        if (DEEP) issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k); else issue(s_bp, pb[1], s_ldb, nxt + OFF_B1, s_k);
+        if (DEEP) issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k); else issue(s_bp, pb[1], s_ldb, nxt_u + OFF_B1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -819,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
           for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[2 * AF + f][2 + c]);
 
       if (more) {
-        if (DEEP) issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k); else issue(s_ap, pa[1], s_lda, nxt + OFF_A1, s_k);
+        if (DEEP) issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k); else issue(s_ap, pa[1], s_lda, nxt_u + OFF_A1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -835,9 +848,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       st ^= 1;
     }
 
-    // epilogue: D block (f, j) of 16x16: lane owns column l15 = lane & 15 and rows 4 q .. 4 q + 3; 64-byte row segments per lane group
-    if (GROUPED) {  // raw accumulators into this piece's dense 256x256 block (edge rows / columns hold clamped duplicates: ignored)
-      float* blk = slabs + ((int64_t)split * grp.tile_base[grp.count] + e_tile) * (BM * BN);
+    // epilogue: D block (f, j) of 16x16: lane owns column l15 = lane & 15 and rows 4 q .. 4 q + 3; 64-byte row segments per lane group.
+    // The item's coordinates are looked up again here instead of being carried through the K loop: every scalar that lives across
+    // the loop costs the staging pointers their registers (SGPR spills in the loop: -20 % on the grouped launch).
+    int i0, j0, kbeg, kend, split;
+    coords(item, i0, j0, kbeg, kend, split);
+    const int e_tile = c_tile, e_prob = c_prob;
+    if (GROUPED && split >= 0) {  // raw accumulators into this piece's dense 256x256 block (edge rows / columns hold clamped duplicates: ignored)
+      float* blk = slabs + ((int64_t)split * g_nrem + (e_tile - grp.n_full)) * (BM * BN);
       // one lane offset + a wave-uniform base per store (128 precomputed per-lane addresses spilled to scratch)
       const unsigned lane_off = (unsigned)(((wm * TM + 4 * q) * BN + wn * TN + (lane & 15)) * 4);
 #pragma unroll
@@ -852,20 +870,43 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     }
     const bool direct = split < 0;  // workgroup-uniform
     const int mrem = M - rfull * BM;
-    float* out = direct ? C : slabs + ((int64_t)split * mrem - (int64_t)rfull * BM) * N;
-    const int64_t ld = direct ? ldc : N;
-    const float scl = direct ? alpha : 1.f;
-    const bool rmw = direct && accumulate;
+    // GROUPED reaches this point with whole-K tiles only: the problem's own output, alpha and accumulate flag
+    int Mo = M, No = N;
+    float* out;
+    int64_t ld;
+    float scl;
+    bool rmw;
+    if constexpr (GROUPED) {
+      Mo = grp.M[e_prob];
+      No = grp.N[e_prob];
+      out = gout.C[e_prob];
+      ld = (int64_t)gout.ldc[e_prob];
+      // alpha through the scalar unit: a vector load here is hoisted above the slab / direct branch by hipcc, stays "pending" on
+      // the slab path and costs a draining s_waitcnt vmcnt(0) at the top of every K-tile of the next item (-20 %)
+      const float* ap = gout.alpha[e_prob];
+      scl = 1.f;
+      if (ap != nullptr) {
+        unsigned bits;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bits) : "s"(ap) : "memory");
+        scl = __builtin_bit_cast(float, bits);
+      }
+      rmw = gout.accumulate[e_prob] != 0;
+    } else {
+      out = direct ? C : slabs + ((int64_t)split * mrem - (int64_t)rfull * BM) * N;
+      ld = direct ? ldc : N;
+      scl = direct ? alpha : 1.f;
+      rmw = direct && accumulate;
+    }
 #pragma unroll
     for (int f = 0; f < 4 * AF; ++f) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = j0 + wn * TN + j * 16 + (lane & 15);
-        if (col >= N) continue;
+        if (col >= No) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = i0 + wm * TM + f * 16 + 4 * q + r;
-          if (row >= M) continue;
+          if (row >= Mo) continue;
           float* dst = out + (int64_t)row * ld + col;
           const float v = acc4[f][j][r] * scl;
           *dst = rmw ? *dst + v : v;
@@ -913,29 +954,23 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   // deep-prefetch ring + offset wave groups (see gemm_nt_big_kernel): each alone measured equal to the plain ring in the step, together
   // +0.8 % end to end (round 1, run 34)
   hipLaunchKernelGGL((gemm_tn_big_kernel<true, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
-                     rfull, accumulate, alpha_dev, tm, tn, TnGroup{});
+                     rfull, accumulate, alpha_dev, tm, tn, TnGroup{}, TnGroupOut{});
 }
 
 // ---- grouped TN (dW of one transformer block in one stream-K launch) ----------------------------------------------
-struct TnGroupOut {
-  float* C[PLM_TN_GROUP_MAX];
-  int64_t ldc[PLM_TN_GROUP_MAX];
-  const float* alpha[PLM_TN_GROUP_MAX];
-  int accumulate[PLM_TN_GROUP_MAX];
-};
 
-// C_p[tile rows/cols] (+)= alpha_p * sum of the tile's pieces; one workgroup per (tile, 16-row group)
-__global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const float* __restrict__ ws, TnGroup grp, TnGroupOut out, int nkt) {
-  const int t = blockIdx.x >> 4, rg = blockIdx.x & 15;
+// C_p[tile rows/cols] (+)= alpha_p * sum of the tile's pieces, for the split tiles n_full .. ntiles-1; one workgroup per
+// (tile, 16-row group)
+__global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const float* __restrict__ ws, TnGroup grp, TnGroupOut out) {
+  const int r_ = blockIdx.x >> 4, rg = blockIdx.x & 15;
+  const int t = grp.n_full + r_;
   int pidx = 0;
 #pragma unroll
   for (int q = 1; q < PLM_TN_GROUP_MAX; ++q)
     if (q < grp.count && t >= grp.tile_base[q]) pidx = q;
   const int local = t - grp.tile_base[pidx];
   const int i0 = (local / grp.tiles_n[pidx]) * 256, j0 = (local % grp.tiles_n[pidx]) * 256;
-  const int ntiles = grp.tile_base[grp.count];
-  const int cf = grp.splits > 0 ? 0 : (t * nkt) / grp.L;
-  const int cl = grp.splits > 0 ? grp.splits - 1 : min(((t + 1) * nkt - 1) / grp.L, grp.nchunks - 1);
+  const int nrem = grp.tile_base[grp.count] - grp.n_full;
   const float a = out.alpha[pidx] ? *out.alpha[pidx] : 1.f;
   const int M = grp.M[pidx], N = grp.N[pidx];
   float* C = out.C[pidx];
@@ -947,9 +982,9 @@ __global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const float* __r
     const int r = rg * 16 + (e >> 6), c = (e & 63) * 4;
     const int row = i0 + r, col = j0 + c;
     if (row >= M || col >= N) continue;        // N % 8 == 0: the four columns are in range together
-    const float* src = ws + (int64_t)t * 65536 + r * 256 + c;
+    const float* src = ws + (int64_t)r_ * 65536 + r * 256 + c;
     f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
-    for (int k = 1; k <= cl - cf; ++k) v += *reinterpret_cast<const f32x4_t*>(src + (int64_t)k * ntiles * 65536);
+    for (int k = 1; k < grp.splits; ++k) v += *reinterpret_cast<const f32x4_t*>(src + (int64_t)k * nrem * 65536);
     v *= a;
     float* dst = C + (int64_t)row * ldc + col;
     if (acc) v += *reinterpret_cast<const f32x4_t*>(dst);
@@ -957,7 +992,6 @@ __global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const float* __r
   }
 }
 
-// plan shared by the workspace query and the launch: tiles per problem, run length, slab count
 static bool tn_group_plan(const int64_t* Ms, const int64_t* Ns, int count, int64_t K, TnGroup* g, int* nslabs) {
   if (g_num_cus == 0) {
     int dev = 0;
@@ -977,30 +1011,36 @@ static bool tn_group_plan(const int64_t* Ms, const int64_t* Ns, int count, int64
   }
   g->tile_base[count] = base;
   g->count = count;
-  const int64_t nkt = K / 64, total = (int64_t)base * nkt;
+  const int64_t nkt = K / 64;
   const int slots = persistent_slots();
-  // uniform split-K over all problems: the number of splits whose item count fills whole rounds best, >= 8 K-tiles each
+  // whole-K tiles for the full rounds; the remainder is split over K with the count that fills its rounds best (>= 8 K-tiles per
+  // piece, mild bias against slab traffic).  Fewer than `slots` tiles: everything is remainder (plain split-K).
+  const int nfull = (base / slots) * slots, nrem = base - nfull;
   int best = 1;
-  double best_eff = 0.0;
-  for (int sp = 1; sp <= 32 && nkt / sp >= 8; ++sp) {
-    const double eff = round_efficiency((int64_t)sp * base, slots) * (sp == 1 ? 1.0 : (1.0 - 0.01 * sp));  // mild bias against slab traffic
-    if (eff > best_eff + 1e-9) {
-      best_eff = eff;
-      best = sp;
+  if (nrem > 0) {
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= 32 && (sp == 1 || nkt / sp >= 8); ++sp) {
+      const int64_t L = plm_cdiv(nkt, sp);
+      const int64_t rounds = plm_cdiv((int64_t)sp * nrem, slots);
+      const double cost = (double)(rounds * L) * (1.0 + 0.01 * (sp - 1));  // K-tiles of wall time for the remainder
+      if (cost < best_cost - 1e-9) {
+        best_cost = cost;
+        best = sp;
+      }
     }
   }
-  g->splits = best;
+  g->n_full = nfull;
+  g->splits = nrem > 0 ? best : 0;
   g->L = (int)plm_cdiv(nkt, best);
-  g->nchunks = (int)((int64_t)best * base < slots ? (int64_t)best * base : slots);
-  *nslabs = best;
-  return total < (1ll << 30);
+  *nslabs = nrem > 0 ? best * nrem : 0;  // dense 256x256 fp32 blocks
+  return (int64_t)base * nkt < (1ll << 30);
 }
 
 extern "C" size_t plm_gemm_tn_grouped_workspace_bytes(const int64_t* Ms, const int64_t* Ns, int count, int64_t K) {
   TnGroup g{};
   int ns = 0;
   if (!Ms || !Ns || !tn_group_plan(Ms, Ns, count, K, &g, &ns)) return 0;
-  return (size_t)ns * (size_t)g.tile_base[count] * 65536 * sizeof(float);
+  return (size_t)ns * 65536 * sizeof(float) + 16;  // never zero: 0 means "unsupported shapes"
 }
 
 extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, int64_t K, void* workspace, size_t workspace_bytes,
@@ -1015,31 +1055,35 @@ extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, 
     PLM_REQUIRE(q.A && q.B && q.C, "plm_gemm_bf16_tn_grouped: null pointer in problem %d", p);
     PLM_REQUIRE(q.M % 8 == 0 && q.N % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N,
                 "plm_gemm_bf16_tn_grouped: problem %d: M, N, lda, ldb must be multiples of 8, ldc of 4", p);
+    PLM_REQUIRE(q.lda < (1ll << 31) && q.ldb < (1ll << 31) && q.ldc < (1ll << 31), "plm_gemm_bf16_tn_grouped: problem %d: row strides must fit 31 bits", p);
     PLM_REQUIRE(((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B) | reinterpret_cast<uintptr_t>(q.C)) & 15) == 0,
                 "plm_gemm_bf16_tn_grouped: problem %d: base pointers must be 16-byte aligned", p);
     Ms[p] = q.M;
     Ns[p] = q.N;
     g.A[p] = q.A;
     g.B[p] = q.B;
-    g.lda[p] = q.lda;
-    g.ldb[p] = q.ldb;
+    g.lda[p] = (int)q.lda;
+    g.ldb[p] = (int)q.ldb;
     o.C[p] = q.C;
-    o.ldc[p] = q.ldc;
+    o.ldc[p] = (int)q.ldc;
     o.alpha[p] = q.alpha_dev;
     o.accumulate[p] = q.accumulate;
   }
   int ns = 0;
   PLM_REQUIRE(tn_group_plan(Ms, Ns, count, K, &g, &ns), "plm_gemm_bf16_tn_grouped: unsupported shapes (K %% 64 == 0, M, N multiples of 8)");
-  const size_t need = (size_t)ns * (size_t)g.tile_base[count] * 65536 * sizeof(float);
+  const size_t need = (size_t)ns * 65536 * sizeof(float);
   if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) {
     plm_set_error("plm_gemm_bf16_tn_grouped: workspace of %zu bytes (16-byte aligned) required, %zu given", need, workspace_bytes);
     return PLM_E_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)g.nchunks), dim3(512), 0, s, nullptr, 0, nullptr, 0, nullptr, 0,
-                     (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g);
-  hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3((unsigned)(g.tile_base[count] * 16)), dim3(256), 0, s, (const float*)workspace, g, o,
-                     (int)(K / 64));
+  const int nrem = g.tile_base[count] - g.n_full;
+  const int64_t nitems = g.n_full + (int64_t)nrem * g.splits;
+  const int slots = persistent_slots();
+  hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)(nitems < slots ? nitems : slots)), dim3(512), 0, s, nullptr, 0, nullptr, 0,
+                     nullptr, 0, (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g, o);
+  if (nrem > 0)
+    hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3((unsigned)(nrem * 16)), dim3(256), 0, s, (const float*)workspace, g, o);
   PLM_CHECK_LAUNCH("plm_gemm_bf16_tn_grouped");
   return PLM_OK;
 }

@@ -155,6 +155,17 @@ __device__ __forceinline__ void dma16_saddr_asm(const void* uniform_base, unsign
                : "memory");
 }
 
+// The same with the LDS destination as a byte address (wave-uniform integer): no generic -> LDS pointer cast per issue (hipcc turns
+// that cast into a compare against the shared aperture, and mis-selects it when it believes the pointer divergent).
+__device__ __forceinline__ void dma16_saddr_u32(const void* uniform_base, unsigned lane_byte_off, unsigned lds_wave_addr) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(uniform_base), "s"(dst)
+               : "memory");
+}
+
 // Values of lane l and lane l^32 as a pair (lower-half value, upper-half value) in every lane, by one
 // v_permlane32_swap (gfx950): a cross-half reduction without the LDS round trip of ds_bpermute.
 __device__ __forceinline__ void half_pair(float v, float& lo, float& hi) {

@@ -24,10 +24,13 @@ class GradSink:
     self.enabled = False
     self.written = set()
     self.on_ready = None  # callable(param) or None
-    # Weight gradients of bias-free Linears have no consumer inside backward, so they are queued and issued `dw_group` at a
-    # time (= the four projections of one transformer block) as ONE grouped split-K launch (ops.gemm_tn_grouped): whole
-    # rounds of work items on all CUs and one reduce instead of four (measured -8 % on the block's dW time).
-    self.dw_group = 4
+    # Weight gradients of bias-free Linears have no consumer inside backward, so they are queued and issued several at a
+    # time as ONE grouped launch (ops.gemm_tn_grouped): whole-K tiles for the full rounds of the persistent grid, split-K only
+    # for the remainder.  The more problems per launch the smaller that remainder (one block = 108 tiles is all remainder:
+    # 0.50 ms; three blocks 0.41 ms per block; six blocks 0.40), but the later the gradients exist: with a gradient consumer
+    # attached (DDP buckets, `on_ready`) a group is three transformer blocks (85 MB of gradients, about one 64 MiB bucket and a
+    # half), without one it is six.
+    self.dw_group_local, self.dw_group_ddp = 24, 12
     self.dw_queue = []
     # RMSNorm weight gradients: the backward kernel leaves per-block partial sums; their column sums (25 launch-bound
     # kernels at the 160M size) are queued and run as ONE launch when backward reaches the embedding (flush_dw)
@@ -40,7 +43,7 @@ class GradSink:
   def defer_dw(self, dy, x, p):
     """Queue dW(p) (+)= dy^T x; runs when the group is full or at flush_dw()."""
     self.dw_queue.append((dy, x, p, not self.first_write(p)))
-    if len(self.dw_queue) >= max(1, self.dw_group):
+    if len(self.dw_queue) >= (self.dw_group_ddp if self.on_ready is not None else self.dw_group_local):
       self._flush_linear_dw()
 
   def defer_norm_dw(self, part, p):

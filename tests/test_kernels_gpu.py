@@ -355,10 +355,14 @@ def test_gemm_tn(ops, M, N, K):
     ([(136, 72), (520, 264)], 1024),                                 # ragged tiles
     ([(256, 256)], 64),                                              # one problem, one K-tile
     ([(768, 768), (8, 8), (1000, 392)], 4096),
+    # 24 problems = six 160M blocks: 648 tiles = two whole-K rounds written directly + 136 tiles split over K
+    ([(768, 2048), (4096, 768), (768, 768), (2304, 768)] * 6, 2048),
+    # 6 ragged problems whose 262 tiles straddle the whole-K / split boundary inside one problem
+    ([(1000, 1032), (520, 264), (2304, 768), (136, 72), (3000, 1544), (4096, 776)], 1024),
 ])
 def test_gemm_tn_grouped(ops, shapes, K):
-  """Grouped stream-K dW launch == the individual GEMMs: every problem, overwrite and accumulate, device alpha; bit-equal to
-  the single-problem kernel on exactly-representable inputs."""
+  """Grouped dW launch (whole-K tiles for the full rounds + split-K remainder) == the individual GEMMs: every problem, overwrite
+  and accumulate, device alpha; bit-equal to the single-problem kernel on exactly-representable inputs."""
   g = torch.Generator(device='cuda').manual_seed(K + len(shapes))
   As = [bf(torch.randn(K, M, generator=g, device='cuda')) for M, _ in shapes]
   Bs = [bf(torch.randn(K, N, generator=g, device='cuda')) for _, N in shapes]

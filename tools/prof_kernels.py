@@ -57,19 +57,20 @@ def main():
     if lib.plm_gemm_tn_workspace_bytes(m, n, k) > 0:
       entry(name + ' (split-K reduce)', 'splitk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
     del A, Bm, out
-  # the four dW GEMMs of a block as the engine issues them: one grouped launch + one reduce
+  # the dW GEMMs of six blocks as the engine issues them on one GPU: one grouped launch (whole-K tiles + split remainder) + one reduce
   gp = []
-  for name in ('tn dW qkv', 'tn dW out', 'tn dW fc1', 'tn dW fc2'):
-    m, n, k = TN[name]
-    gp.append((torch.randn(k, m, device='cuda').to(BF), torch.randn(k, n, device='cuda').to(BF), torch.zeros(m, n, device='cuda'), False, None))
+  for _blk in range(6):
+    for name in ('tn dW fc2', 'tn dW fc1', 'tn dW out', 'tn dW qkv'):
+      m, n, k = TN[name]
+      gp.append((torch.randn(k, m, device='cuda').to(BF), torch.randn(k, n, device='cuda').to(BF), torch.zeros(m, n, device='cuda'), False, None))
   torch.cuda.synchronize()
   for _ in range(2):
     assert ops.gemm_tn_grouped(gp)
   torch.cuda.synchronize()
   fl = sum(2.0 * a.shape[1] * b.shape[1] * a.shape[0] for a, b, *_ in gp)
   alg = sum(2.0 * (a.numel() + b.numel()) + 4.0 * o.numel() for a, b, o, *_ in gp)
-  entry('tn dW block (grouped x4)', 'gemm_tn', fl, alg, K=M)
-  entry('tn dW block (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of='tn dW block (grouped x4)')
+  entry('tn dW 6 blocks (grouped x24)', 'gemm_tn', fl, alg, K=M)
+  entry('tn dW 6 blocks (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of='tn dW 6 blocks (grouped x24)')
   del gp
   # attention: the step's inputs have the statistics of a freshly initialised model (projection outputs ~N(0, 0.4))
   qkv = (0.4 * torch.randn(M, 3 * d, device='cuda')).to(BF)
