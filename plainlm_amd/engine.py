@@ -171,9 +171,9 @@ class HipEngine(torch.nn.Module):
     self.intra_doc_masking = getattr(cfg, 'intra_doc_masking', False)
     self.device = device
     self._stager = _Stager()
-    # 'Train loss is nan' (engine.py:116-117).  The reference reads the loss on the host before it enqueues backward; the host is
-    # close to launch-bound on this path (~250 launches per micro-step), so that read - a wait for the whole forward with an
-    # empty queue behind it - costs 4-8 ms of a 35 ms step (tools/engine_bench.py: 42.2 vs 34.9 ms).  Default nan_check_lag = 1:
+    # 'Train loss is nan' (engine.py:116-117).  The reference reads the loss on the host before it enqueues backward: a wait for
+    # the whole forward with an empty launch queue behind it, every micro-step - measured +5.5 ms on a 34 ms step
+    # (tools/engine_bench.py --nan-check-lag 0).  Default nan_check_lag = 1:
     # the flag of micro-step k (one pinned byte with its own event) is read AFTER k's backward has been enqueued - at the window's
     # last micro-step, before clip + AdamW, or at the submission of micro-step k + 1 - by which time the forward has long
     # finished.  The error is raised from the same step() call when k ends a window (always, with accumulation 1) and from the
