@@ -106,9 +106,8 @@ int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
                      int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream);
 /* same as plm_gemm_bf16_nt with an explicit kernel choice (autotuning / A-B measurements / tests):
  * variant 0 = automatic, 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA double-buffered,
- * 3 = persistent 256x256, plain 4-phase LDS-DMA ring,
  * 4 / 5 / 6 = persistent 256x256 / 256x192 / 256x128 with the deep-prefetch ring (half-tile slots refilled two K-tiles
- *             ahead) and offset wave groups - the kernels the automatic policy chooses from
+ *             ahead) and offset wave groups - the kernels the automatic policy chooses from; 3 = 4 (kept for callers of round 1)
  * (3..6: bf16 C, no accumulate; 2..6: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
 int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,

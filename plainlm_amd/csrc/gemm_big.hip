@@ -75,11 +75,7 @@ static double round_efficiency(int64_t tiles, int slots) {
   return (double)tiles / (double)(rounds * slots);
 }
 
-// STAG: every phase is split into a READ section (DMA issue, ds_reads, counted vmcnt wait) and an MFMA section with a
-// barrier after each; the wave group wm-odd runs one barrier behind the other (waves w and w+4 share a SIMD and sit in
-// different groups), so one group's LDS reads overlap the other group's MFMAs; s_setprio(1) around the MFMA cluster.
-// Used by the hybrid (whole-K + stream-K) launch of the long-K lm_head dX GEMM, where it is the fastest schedule in the step.
-// Hybrid work items: the tiles of the first `rfull` tile rows take the whole contraction and write bf16 C (whole
+// Hybrid work items (HYB): the tiles of the first `rfull` tile rows take the whole contraction and write bf16 C (whole
 // rounds of the persistent grid); the K-tiles of the remaining tile rows form ONE stream (tile-major, then k) that is
 // cut into `nchunks` equal runs of `L` K-tiles, one run per workgroup ("stream-K" for the last, partial round).  A run
 // may cross a tile boundary, so it is executed as up to ceil(L/nkt)+1 PIECES; every piece writes raw fp32
@@ -93,16 +89,17 @@ struct HybridArgs {
   float* slabs;
 };
 
-// DEEP (4-phase schedule only): a half-tile slot is refilled as soon as the phase that read it has ended, with the
-// half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups
-// (80 KiB for 256x256) are in flight behind every counted wait instead of two.  Measured (profiles/r01_kbench_run19*):
-// global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deeper queue lets them overlap.
+// Schedule (one form; the plain ring, the staggered-barrier form and the one-barrier form of round 1 are gone): a half-tile slot
+// is refilled as soon as the phase that read it has ended, with the half-tile of the K-tile TWO ahead (phase 1: A1 of kt+1,
+// phases 2/3/4: A0/B0/B1 of kt+2), so five LDS-DMA groups (80 KiB for 256x256) are in flight behind every counted wait.
+// Measured (profiles/r01_kbench_run19*): global->LDS fill and LDS->MFMA compute each take ~70 % of the kernel alone; the deep
+// queue lets them overlap.
 // MFMA shape: v_mfma_f32_16x16x32_bf16 (16-row fragments, two K-steps of 32 per K-tile; lane = row l15 of a 16-row block, K-chunk
 // q = lane >> 4).  The GEMMs of the step run at the board's power limit, not at an issue limit (tools/power_probe.py: the same launch
 // on zero operands is 17-41 % faster); per flop this shape moves a quarter of the accumulator registers of 32x32x16 per instruction
 // and measured 7-12 % more flops under the cap (tools/ubench/mfma_power.hip), +4-10 % on every NT shape of the step, for the same
 // ds_read_b128 count and bytes and twice the MFMA instructions.
-template <int BM, int BN, int WM, int WN, bool STAG, bool HYB = false, bool DEEP = false, bool OFFS = false>
+template <int BM, int BN, int WM, int WN, bool HYB = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -121,36 +118,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   constexpr int A_DMA = A_ROWS / 64, B0_DMA = B0_ROWS / 64, B1_DMA = B1_ROWS / 64;  // LDS-DMA instructions per thread per half-tile
   static_assert(B0_DMA >= B1_DMA && B1_DMA >= 1, "half-tiles are whole DMA rounds of the workgroup");
   constexpr int OFF_A0 = 0, OFF_B0 = A_HT, OFF_B1 = A_HT + B0_HT, OFF_A1 = A_HT + B0_HT + B1_HT;
-  constexpr int W_P4 = A_DMA + B1_DMA;  // end of phase 4: B1', A1' may stay in flight
-  constexpr int W_P1 = 2 * A_DMA;       // end of phase 1: A1', A0'' may stay in flight
-  constexpr int W_P2 = A_DMA + B0_DMA;  // end of phase 2: A0'', B0'' may stay in flight
-  static_assert(!DEEP || !STAG, "DEEP is a variant of the plain 4-phase schedule");
-  // DEEP: groups younger than the one a wait retires (see the schedule above)
+  // LDS-DMA instructions younger than the group a wait retires (see the schedule above)
   constexpr int D_P4 = 2 * A_DMA + B0_DMA + 2 * B1_DMA;  // end of phase 4 -> A0, B0 of kt+1: B1', A1', A0'', B0'', B1'' in flight
   constexpr int D_P1 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 1 -> B1 of kt: A1, A0', B0', B1', A1' in flight
   constexpr int D_P2 = 3 * A_DMA + B0_DMA + B1_DMA;      // end of phase 2 -> A1 of kt: A0', B0', B1', A1', A0'' in flight
-  // OFFS (offset wave groups, deep ring only): waves w and w+4 share a SIMD.  With every wave on the same schedule both do their
+  // Offset wave groups: waves w and w+4 share a SIMD.  With every wave on the same schedule both do their
   // DMA issue + LDS reads at the same time and then queue for the matrix pipe: a phase costs overhead + 2 x MFMA time.  Here the
   // second group (waves 4-7) takes each barrier BETWEEN the reads and the MFMAs of a phase instead of behind the MFMAs - same
   // code, same three barriers per K-tile and wave, same slots and waits - so inside every barrier interval group 0 runs
   // reads(p), MFMAs(p) while group 1 runs MFMAs(p-1), reads(p): one wave's reads and DMA issue sit under the other's MFMAs.
-  static_assert(!OFFS || DEEP, "OFFS is a variant of the 4-phase deep-prefetch ring");
-  // DEEP: the C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
+  // The C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
   constexpr int NS = 2 * AF * 2 * NBF;
-  static_assert(!DEEP || D_P1 + NS < 64, "vmcnt is a 6-bit counter");
+  static_assert(D_P1 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const bool grp1 = OFFS && (wave >> 2) != 0;  // wave-uniform
+  const bool grp1 = (wave >> 2) != 0;  // wave-uniform
   // Waves w and w+4 share a SIMD, and instruction issue is arbitrated by priority, then age: at equal priority the second-dispatched
   // half (waves 4-7) loses every arbitration.  ONE static s_setprio for that half, no per-phase flips: +1.6 % end to end (run 40).
-#ifndef PLM_NO_PRIO_HALF
-  if (!STAG && wave >= 4) __builtin_amdgcn_s_setprio(1);  // (the staggered schedule flips priorities per section itself)
-#endif
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int l15 = lane & 15, q = lane >> 4;  // fragment coordinates: row inside a 16-row block, K-chunk
   // HYB = false instantiations keep the plain schedule free of the stream-K bookkeeping
   const int rfull = HYB ? hyb.rfull : tiles_m;
@@ -269,13 +259,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       set_ptrs(m0, n0);
       s_ak = s_ab + s_k;
       s_bk = s_bb + s_k;
-    } else if (DEEP) {  // nothing left: stay on the last K-tile (DEEP keeps issuing - see `more` in the K loop)
+    } else {  // nothing left: stay on the last K-tile (the ring keeps issuing - see the K loop)
       s_k -= 64;
       s_ak -= 64;
       s_bk -= 64;
     }
   };
-  int s_st = 0;  // DEEP: stage buffer of the K-tile under the staging cursor
+  int s_st = 0;  // stage buffer of the K-tile under the staging cursor
   auto advance_staged = [&]() {
     s_k += 64;
     s_ak += 64;
@@ -298,19 +288,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     issue_a(1, smem, s_k);
     advance_staged();
   }
-  if (DEEP) {  // plus A0, B0, B1 of the second K-tile (its A1 follows in phase 1 of the first)
+  {  // plus A0, B0, B1 of the second K-tile (its A1 follows in phase 1 of the first)
     issue_a(0, smem + STAGE, s_k);
     issue_b(0, smem + STAGE, s_k);
     issue_b(1, smem + STAGE, s_k);
     wait_vm<D_P4>();
-  } else {
-    wait_vm<0>();
   }
   phase_barrier();
-  if (STAG && (wm & 1)) phase_barrier();  // odd wave group runs one barrier behind
 
   int st = 0;
-  bool credit = false;  // DEEP: NS stores of the previous tile's epilogue are still counted by vmcnt
+  bool credit = false;  // NS stores of the previous tile's epilogue are still counted by vmcnt
   int credit_i = 0;     // the same flag as a scalar register operand of wait_vm_sel
   Cur cc;
   cur_init(cc, first);
@@ -329,45 +316,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
-      // workgroup-uniform: the staging cursor still points at a K-tile.  DEEP: constant - when a workgroup runs out of K-tiles it
-      // re-stages its last one into slots nobody reads again (a few KiB of L2 hits per workgroup), so the DMA issue and the
-      // counted waits of the loop carry no conditionals; the loads are drained before the kernel ends.
-      bool more = DEEP || s_item < ntiles;
+      // The staging cursor never runs dry: when a workgroup is out of K-tiles it re-stages its last one into slots nobody reads
+      // again (a few KiB of L2 hits per workgroup), so the DMA issue and the counted waits of the loop carry no conditionals;
+      // the loads are drained before the kernel ends.
       const char* cur = smem + st * STAGE;
-      char* nxt = smem + (st ^ 1) * STAGE;
       bf16x8_t a6[2 * AF][2], b06[2 * BF0][2], b16[2][2];  // fragments: [16-row block][K-step of 32]
-      // end of a phase's READ section / MFMA section
-      auto end_read = [&](auto wtag) {
+      // end of a phase: counted wait for the half-tile the next phase reads (+ the previous epilogue's stores while they are
+      // still counted), then the workgroup barrier
+      auto end_phase = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
-        // one scalar compare on the common path (the nested form cost ~10 scalar instructions and three branches per wait)
-        if (!more) wait_vm<0>();
-        else if (DEEP) wait_vm_sel<W, DEEP ? W + NS : W>(credit_i);
-        else wait_vm<W>();
-        if (STAG) {  // barrier first: the LDS reads of this section land while the wave waits for the other group
-          asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_setprio(1);
-        } else {
-          phase_barrier();
-        }
-      };
-      auto end_mfma = [&]() {
-        if (STAG) {
-          __builtin_amdgcn_s_setprio(0);
-          asm volatile("s_barrier" ::: "memory");
-        }
+        wait_vm_sel<W, W + NS>(credit_i);
+        phase_barrier();
       };
       using std::integral_constant;
 
-      // ---- phase 1: quadrant (A0, B0); stage A0 of the next item (DEEP: A1 of the next item, then move the cursor on)
-      if (DEEP) {
-        if (more) {
-          issue_a(1, smem + s_st * STAGE, s_k);
-          advance_staged();
-          more = DEEP || s_item < ntiles;
-        }
-      } else if (!STAG && more) {
-        issue_a(0, nxt, s_k);
-      }
+      // ---- phase 1: quadrant (A0, B0); stage A1 of the next K-tile, then move the cursor on
+      issue_a(1, smem + s_st * STAGE, s_k);
+      advance_staged();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -375,88 +340,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = frag16(cur + OFF_A0, wm * AH + f * 16 + l15, ks);
       }
-      if (STAG) {
-        if (more) issue_a(0, nxt, s_k);  // behind the reads: their latency hides the DMA issue
-        end_read(integral_constant<int, W_P1>{});
-      }
-      if (OFFS && grp1) end_read(integral_constant<int, D_P1>{});
+      if (grp1) end_phase(integral_constant<int, D_P1>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
           for (int j = 0; j < 2 * BF0; ++j) acc4[f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[f][j]);
-      if (STAG) end_mfma(); else if (!grp1) end_read(integral_constant<int, DEEP ? D_P1 : W_P1>{});
+      if (!grp1) end_phase(integral_constant<int, D_P1>{});
 
-      // ---- phase 2: quadrant (A0, B1); stage B0 (DEEP: A0 two K-tiles ahead, into the slot phase 1 just read)
-      if (DEEP) {
-        if (more) issue_a(0, smem + s_st * STAGE, s_k);
-      } else if (!STAG && more) {
-        issue_b(0, nxt, s_k);
-      }
+      // ---- phase 2: quadrant (A0, B1); stage A0 two K-tiles ahead, into the slot phase 1 just read
+      issue_a(0, smem + s_st * STAGE, s_k);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int c = 0; c < 2; ++c) b16[c][ks] = frag16(cur + OFF_B1, wn * 32 + c * 16 + l15, ks);
-      if (STAG) {
-        if (more) issue_b(0, nxt, s_k);
-        end_read(integral_constant<int, W_P2>{});
-      }
-      if (OFFS && grp1) end_read(integral_constant<int, D_P2>{});
+      if (grp1) end_phase(integral_constant<int, D_P2>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[f][2 * BF0 + c]);
-      if (STAG) end_mfma(); else if (!grp1) end_read(integral_constant<int, DEEP ? D_P2 : W_P2>{});
+      if (!grp1) end_phase(integral_constant<int, D_P2>{});
 
-      // ---- phase 3: quadrant (A1, B1); stage B1 (DEEP: B0).  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
-      if (DEEP) {
-        if (more) issue_b(0, smem + s_st * STAGE, s_k);
-      } else if (!STAG && more) {
-        issue_b(1, nxt, s_k);
-      }
+      // ---- phase 3: quadrant (A1, B1); stage B0.  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
+      issue_b(0, smem + s_st * STAGE, s_k);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = frag16(cur + OFF_A1, wm * AH + f * 16 + l15, ks);
-      if (STAG) {
-        if (more) issue_b(1, nxt, s_k);
-        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-      }
-      if (OFFS && grp1) end_read(integral_constant<int, D_P4 - B1_DMA>{});  // B1'' is only issued in phase 4
+      if (grp1) end_phase(integral_constant<int, D_P4 - B1_DMA>{});  // B1'' is only issued in phase 4
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[2 * AF + f][2 * BF0 + c]);
-      if (STAG) end_mfma();
 
-      // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage A1 (DEEP: B1)
-      if (DEEP) {
-        if (more) issue_b(1, smem + s_st * STAGE, s_k);
-      } else if (more) {
-        issue_a(1, nxt, s_k);
-      }
-      if (STAG) {
-        if (more) advance_staged();
-        end_read(integral_constant<int, W_P4>{});
-      }
+      // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage B1
+      issue_b(1, smem + s_st * STAGE, s_k);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
           for (int j = 0; j < 2 * BF0; ++j) acc4[2 * AF + f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[2 * AF + f][j]);
-      if (STAG) {
-        end_mfma();
-      } else {
-        if (!DEEP && more) advance_staged();
-        if (!grp1) end_read(integral_constant<int, DEEP ? D_P4 : W_P4>{});
-      }
+      if (!grp1) end_phase(integral_constant<int, D_P4>{});
       credit = false;
       credit_i = 0;
       st ^= 1;
@@ -516,11 +446,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
-    credit = DEEP && m0 + BM <= M && n0 + BN <= N;  // interior tile: every wave issued exactly NS stores
+    credit = m0 + BM <= M && n0 + BN <= N;  // interior tile: every wave issued exactly NS stores
     credit_i = __builtin_amdgcn_readfirstlane(credit ? 1 : 0);
   }
-  if (DEEP) wait_vm<0>();  // the re-staged tail loads write this workgroup's LDS: they must have landed before the last wave leaves
-  if (STAG && !(wm & 1)) phase_barrier();  // balances the extra barrier of the odd group
+  wait_vm<0>();  // the re-staged tail loads write this workgroup's LDS: they must have landed before the last wave leaves
 }
 
 // =============================================================================================
@@ -535,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 // (C = / += alpha*acc); the tiles of the remaining rows are split `splits` ways over K and write raw fp32 partials
 // into slab[split][row - rfull*256][N], summed by splitk_reduce_kernel.  rfull = 0 is plain split-K (small
 // outputs), splits = 1 with no remainder is plain tiling; the hybrid keeps every CU busy for a whole number of rounds.
-// DEEP: see gemm_nt_big_kernel - half-tile slots are refilled two K-tiles ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1
+// Schedule: see gemm_nt_big_kernel - half-tile slots are refilled two K-tiles ahead (phase 1: A1 of kt+1, phases 2/3/4: A0/B0/B1
 // of kt+2), five LDS-DMA groups in flight behind every counted wait.
 // GROUPED: up to PLM_TN_GROUP_MAX independent problems with the same contraction length (the dW GEMMs of one or more
 // transformer blocks: same token rows, different projections) run as ONE launch over the union of their 256x256 output tiles,
@@ -567,7 +496,7 @@ struct TnGroupOut {
 // four groups of one transpose read touch k-rows 8 apart - the pair rotation takes bit 3 of the k-row as well as its low two bits.
 __device__ __forceinline__ int tn_rot(int k) { return 2 * (k & 3) + ((k >> 3) & 1); }
 
-template <bool DEEP, bool GROUPED = false, bool OFFS = false>
+template <bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                              int64_t ldc, float* __restrict__ slabs, int M, int N, int K, int kchunk,
@@ -579,13 +508,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
   constexpr int HT = 64 * 256;  // one half-tile: 64 k-rows x 128 cols bf16
   constexpr int STAGE = 4 * HT;
   constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT;
-  constexpr int W_ALL = DEEP ? 10 : 4;  // A_DMA = B_DMA = 2: two (DEEP: five) DMA groups stay in flight behind every counted wait
+  constexpr int W_ALL = 10;  // A_DMA = B_DMA = 2: five DMA groups stay in flight behind every counted wait
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const bool grp1 = OFFS && (wave >> 2) != 0;  // wave-uniform; waves w and w+4 share a SIMD
+  const bool grp1 = (wave >> 2) != 0;  // wave-uniform; waves w and w+4 share a SIMD
 #ifndef PLM_NO_PRIO_HALF_TN
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (see gemm_nt_big_kernel)
 #endif
@@ -718,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       s_item += gridDim.x;
     }
   };
-  int s_st = 0;  // DEEP: stage buffer of the K-tile under the staging cursor
+  int s_st = 0;  // stage buffer of the K-tile under the staging cursor
   auto advance_staged = [&]() {
     s_k += 64;
     s_st ^= 1;
@@ -735,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     issue(s_ap, pa[1], s_lda, smem_u + OFF_A1, s_k);
     advance_staged();
   }
-  if (DEEP && s_item < nitems) {  // plus A0, B0, B1 of the second K-tile
+  if (s_item < nitems) {  // plus A0, B0, B1 of the second K-tile
     issue(s_ap, pa[0], s_lda, smem_u + STAGE + OFF_A0, s_k);
     issue(s_bp, pb[0], s_ldb, smem_u + STAGE + OFF_B0, s_k);
     issue(s_bp, pb[1], s_ldb, smem_u + STAGE + OFF_B1, s_k);
@@ -766,18 +695,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       bool more = s_item < nitems;  // workgroup-uniform: the staging cursor still points at a K-tile
       unsigned sst = smem_u + s_st * STAGE;
       const char* cur = smem + st * STAGE;
-      const unsigned nxt_u = smem_u + (st ^ 1) * STAGE;
       bf16x8_t a6[2 * AF][2], b06[2][2], b16[2][2];  // fragments: [16-column block][K-step of 32]
 
-      if (DEEP) {
-        if (more) {
-          issue(s_ap, pa[1], s_lda, sst + OFF_A1, s_k);
-          advance_staged();
-          more = s_item < nitems;
-          sst = smem_u + s_st * STAGE;
-        }
-      } else if (more) {
-        issue(s_ap, pa[0], s_lda, nxt_u + OFF_A0, s_k);
+      if (more) {
+        issue(s_ap, pa[1], s_lda, sst + OFF_A1, s_k);
+        advance_staged();
+        more = s_item < nitems;
+        sst = smem_u + s_st * STAGE;
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -791,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
         phase_barrier();
       };
       using WAll = std::integral_constant<int, W_ALL>;
-      if (grp1) sync(WAll{});  // OFFS: the second wave group's barrier sits between the reads and the MFMAs (see gemm_nt_big_kernel)
+      if (grp1) sync(WAll{});  // the second wave group's barrier sits between the reads and the MFMAs (see gemm_nt_big_kernel)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -801,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       if (!grp1) sync(WAll{});
 
       if (more) {
-        if (DEEP) issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k); else issue(s_bp, pb[0], s_ldb, nxt_u + OFF_B0, s_k);
+        issue(s_ap, pa[0], s_lda, sst + OFF_A0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -817,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
       if (!grp1) sync(WAll{});
 
       if (more) {
-        if (DEEP) issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k); else issue(s_bp, pb[1], s_ldb, nxt_u + OFF_B1, s_k);
+        issue(s_bp, pb[0], s_ldb, sst + OFF_B0, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -832,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
           for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[2 * AF + f][2 + c]);
 
       if (more) {
-        if (DEEP) issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k); else issue(s_ap, pa[1], s_lda, nxt_u + OFF_A1, s_k);
+        issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -840,7 +764,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
         for (int f = 0; f < 2 * AF; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[2 * AF + f][c] = mfma16(a6[f][ks], b06[c][ks], acc4[2 * AF + f][c]);
-      if (more && !DEEP) advance_staged();
       if (!grp1) {
         if (more) wait_vm<W_ALL>(); else wait_vm<0>();
         phase_barrier();
@@ -953,7 +876,7 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
   const dim3 grid(nitems < slots ? nitems : slots), block(512);
   // deep-prefetch ring + offset wave groups (see gemm_nt_big_kernel): each alone measured equal to the plain ring in the step, together
   // +0.8 % end to end (round 1, run 34)
-  hipLaunchKernelGGL((gemm_tn_big_kernel<true, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
+  hipLaunchKernelGGL((gemm_tn_big_kernel<false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, slabs, (int)M, (int)N, (int)K, kchunk, splits,
                      rfull, accumulate, alpha_dev, tm, tn, TnGroup{}, TnGroupOut{});
 }
 
@@ -1080,7 +1003,7 @@ extern "C" int plm_gemm_bf16_tn_grouped(const plm_tn_problem* probs, int count, 
   const int nrem = g.tile_base[count] - g.n_full;
   const int64_t nitems = g.n_full + (int64_t)nrem * g.splits;
   const int slots = persistent_slots();
-  hipLaunchKernelGGL((gemm_tn_big_kernel<true, true, true>), dim3((unsigned)(nitems < slots ? nitems : slots)), dim3(512), 0, s, nullptr, 0, nullptr, 0,
+  hipLaunchKernelGGL((gemm_tn_big_kernel<true>), dim3((unsigned)(nitems < slots ? nitems : slots)), dim3(512), 0, s, nullptr, 0, nullptr, 0,
                      nullptr, 0, (float*)workspace, 0, 0, (int)K, 0, 1, 0, 0, nullptr, 0, 0, g, o);
   if (nrem > 0)
     hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3((unsigned)(nrem * 16)), dim3(256), 0, s, (const float*)workspace, g, o);
@@ -1165,10 +1088,8 @@ extern "C" size_t plm_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
-// variant: 0 = pick by tile-count efficiency (may decline), 3 = 256x256, 4 = 256x128, 5 / 6 = the same, staggered,
-// 7 / 8 = the same with one barrier per K-tile
-// variant: 0 automatic | 3 plain 4-phase ring, 256x256 | 4 / 5 / 6 deep-prefetch ring with offset wave groups on 256x256 / 256x192 /
-// 256x128 tiles (what the automatic policy picks from; explicit numbers exist for the tests and tools/kbench.py).
+// variant: 0 automatic | 4 / 5 / 6 the persistent kernel on 256x256 / 256x192 / 256x128 tiles (what the automatic policy picks from;
+// explicit numbers exist for the tests and tools/kbench.py) | 3 = 4.
 // Returns false when the shape is better served by the 128x128 kernels of gemm.hip.
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, void* workspace, size_t workspace_bytes,
@@ -1201,8 +1122,8 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         const HybridArgs h{p.rfull, p.nchunks, p.L, (float*)workspace};
         const int nitems = p.rfull * tn256 + p.nchunks;
         const dim3 g2(nitems < slots ? nitems : slots);
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true, true, false, false>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                           (int)K, alpha_dev, tm, tn256, h);
+        hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev,
+                           tm, tn256, h);
         const int64_t nv = rem_rows * (N / 8);
         int64_t rb = plm_cdiv(nv, 256);
         if (rb > 4096) rb = 4096;
@@ -1215,27 +1136,17 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
   // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
   if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
-  if (variant == 3) {
-    const int nt_ = tm * tn256;
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false>), dim3(nt_ < slots ? nt_ : slots), block, 0, s, A, lda, B, ldb, C, ldc, (int)M,
-                       (int)N, (int)K, alpha_dev, tm, tn256, hyb);
-    return true;
-  }
-  // the automatic schedule, decided INSIDE the training step (bench.py A/Bs of runs 28-33): the deep-prefetch 4-phase ring with
-  // offset wave groups for every K and all three tile shapes
-  int which = variant - 4;  // 0: 256x256, 1: 256x192, 2: 256x128
+  // one schedule (deep-prefetch 4-phase ring with offset wave groups), three tile shapes; variant 3 is kept as an alias of 4
+  int which = variant <= 4 ? 0 : variant - 4;  // 0: 256x256, 1: 256x192, 2: 256x128
   if (variant == 0) which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
   const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
   const int nt_ = tm * tn_;
   const dim3 g(nt_ < slots ? nt_ : slots);
   if (which == 0)
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                       (int)K, alpha_dev, tm, tn_, hyb);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb);
   else if (which == 1)
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                       (int)K, alpha_dev, tm, tn_, hyb);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb);
   else
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, true, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                       (int)K, alpha_dev, tm, tn_, hyb);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb);
   return true;
 }

@@ -54,10 +54,13 @@ def main():
   ap.add_argument('--B', type=int, default=32)
   ap.add_argument('--T', type=int, default=1024)
   ap.add_argument('--json', default='')
+  ap.add_argument('--cu-reserve', type=int, default=0, help='CUs the persistent GEMMs leave free (what a data-parallel run sets during backward)')
   ap.add_argument('--variants', action='store_true', help='also time every NT kernel variant per shape')
   ap.add_argument('--instep', action='store_true', help='NT variants under in-step conditions: rotating operand sets + an HBM-bound kernel between launches')
   a = ap.parse_args()
   only = set(a.only.split(',')) if a.only else None
+  if a.cu_reserve:
+    ops.set_cu_reserve(a.cu_reserve)
   B, T, d, nh, h, V = a.B, a.T, 768, 12, 2048, 50280
   M = B * T
   dev = 'cuda'
