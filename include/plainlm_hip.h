@@ -158,6 +158,12 @@ int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int
 int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* QKV, int64_t ldq, int64_t M,
                       int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                       void* stream);
+/* fc1 of the SwiGLU MLP with the activation in the GEMM epilogue (models/components.py:50-56):
+ * U[M, 2h] = X[M,K] W[2h,K]^T (gate | up columns, dense, kept for backward) and ACT[M, h] = bf16(bf16(silu(gate)) * up), the
+ * reference's autocast rounding order.  One launch when 2h % 256 == 0, K % 64 == 0, M >= 512; otherwise GEMM + plm_swiglu_fwd
+ * (same bits). */
+int plm_fc1_swiglu_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* U, uint16_t* ACT, int64_t M,
+                        int64_t h, int64_t K, void* stream);
 int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,
                  int64_t hd, void* stream);
 int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,

@@ -17,7 +17,7 @@ _lib = None
 
 # ABI the signatures below were written for (plm_version() of the library must match: a stale .so that still exports every
 # symbol but with other argument lists / struct layouts would corrupt memory instead of raising)
-EXPECTED_ABI = 102
+EXPECTED_ABI = 103
 
 _P = C.c_void_p
 _I64 = C.c_int64
@@ -69,6 +69,7 @@ SIGNATURES = {
   'plm_gemm_bf16_tn_grouped': (_I, [C.POINTER(TnProblem), _I, _I64, _P, _SZ, _P]),
   'plm_rope_qk': (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_qkv_rope_bf16': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
+  'plm_fc1_swiglu_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P]),

@@ -678,8 +678,7 @@ extern "C" int plm_colsum_f32(const float* part, float* out, int64_t rows, int64
 //   s = bf16(silu(x)) ; out = bf16(s * z)
 //   ds = bf16(dout * z) ; dz = bf16(dout * s) ; dx = bf16(ds * sig * (1 + x * (1 - sig)))
 // ===========================================================================
-// v_exp_f32 + v_rcp_f32 (1 ulp each): the result is rounded to bf16 anyway, a full-precision division buys nothing
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return plm_sigmoid(x); }  // plm_device.h (shared with the fc1 GEMM epilogue)
 
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ out, int64_t M,
                                                          int64_t h) {
@@ -693,9 +692,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const uint16_t* __restr
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float xf = bf2f(xv[e]);
-      const bf16_t s = f2bf(xf * sigmoidf_(xf));
-      o[e] = f2bf(bf2f(s) * bf2f(zv[e]));
+      o[e] = plm_swiglu_bf16(xv[e], zv[e]);
     }
     st_bf16x8(out + m * h + c, o);
   }

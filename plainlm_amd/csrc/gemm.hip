@@ -374,6 +374,25 @@ extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t*
   return plm_rope_qk(QKV, rope_cos, rope_sin, B, T, nh, hd, stream);
 }
 
+// fc1 of the SwiGLU MLP with the activation in the GEMM epilogue (models/components.py:50-56):
+//   U[M, 2h] = X[M, K] W[2h, K]^T  (gate | up, kept for backward)  and  ACT[M, h] = bf16(bf16(silu(gate)) * up).
+// One launch on the persistent 256x256 kernel when the shape qualifies (2h % 256 == 0, K % 64 == 0, M >= 512); otherwise the GEMM
+// followed by plm_swiglu_fwd - the two paths produce the same bits.
+bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, uint16_t* act,
+                            int64_t ldact, int64_t M, int64_t N, int64_t K, hipStream_t s);
+extern "C" int plm_fc1_swiglu_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* U, uint16_t* ACT, int64_t M,
+                                   int64_t h, int64_t K, void* stream) {
+  PLM_REQUIRE(X && W && U && ACT, "plm_fc1_swiglu_bf16: null pointer");
+  PLM_REQUIRE(M > 0 && h > 0 && K > 0 && h % 8 == 0, "plm_fc1_swiglu_bf16: bad shape (h %% 8 == 0)");
+  const int64_t N = 2 * h;
+  if (getenv("PLM_GEMM_V1") == nullptr && plm_launch_gemm_nt_glu(X, ldx, W, ldw, U, N, ACT, h, M, N, K, (hipStream_t)stream)) {
+    PLM_CHECK_LAUNCH("plm_fc1_swiglu_bf16");
+    return PLM_OK;
+  }
+  if (int rc = plm_gemm_bf16_nt_ex(X, ldx, W, ldw, U, N, M, N, K, 0, 0, nullptr, 0, stream)) return rc;
+  return plm_swiglu_fwd(U, ACT, M, h, stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // TN   C[i][j] = sum_k A[k][i] B[k][j]
 // ---------------------------------------------------------------------------------------------

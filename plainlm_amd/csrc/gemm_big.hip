@@ -99,12 +99,18 @@ struct HybridArgs {
 // on zero operands is 17-41 % faster); per flop this shape moves a quarter of the accumulator registers of 32x32x16 per instruction
 // and measured 7-12 % more flops under the cap (tools/ubench/mfma_power.hip), +4-10 % on every NT shape of the step, for the same
 // ds_read_b128 count and bytes and twice the MFMA instructions.
-template <int BM, int BN, int WM, int WN, bool HYB = false>
+// GLU (256x256 tile only): B is the fused fc1 weight [2h, K] of a SwiGLU MLP (gate rows 0..h-1, up rows h..2h-1, N = 2h).  A tile's
+// 256 columns are 128 gate columns + the 128 up columns of the same hidden units: half-tile B0 = gate rows, B1 = up rows, so a wave
+// holds gate and up of its 32 hidden units at the same lane / register positions.  The epilogue writes C = fc1 output in its
+// ordinary [gate | up] layout (backward needs it) AND act[M, h] = bf16(bf16(silu(gate)) * up) computed from the rounded values -
+// the bits plm_swiglu_fwd produces - which removes one read of C and one launch per layer (swiglu_fwd: 69 us, 402 MB).
+template <int BM, int BN, int WM, int WN, bool HYB = false, bool GLU = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
-                                                             HybridArgs hyb) {
+                                                             HybridArgs hyb, uint16_t* __restrict__ act, int64_t ldact) {
+  static_assert(!GLU || (BM == 256 && BN == 256 && WN == 4 && !HYB), "GLU epilogue: 256x256 tiles, whole-K items");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   static_assert(WM * WN == 8 && (TN == 64 || TN == 96) && (TM == 128 || TM == 64), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // The C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
-  constexpr int NS = 2 * AF * 2 * NBF;
+  constexpr int NS = 2 * AF * 2 * NBF + (GLU ? 2 * AF * 2 : 0);
   static_assert(D_P1 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   const uint16_t* s_bk = B;
   auto set_ptrs = [&](int m0, int n0) {
     s_ab = A + (int64_t)m0 * lda;
-    s_bb = B + (int64_t)n0 * ldb;
+    s_bb = B + (int64_t)(GLU ? n0 / 2 : n0) * ldb;  // GLU: the tile's first gate row
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         const int rw = h ? 32 : 32 * BF0;  // rows of one wave inside this half-tile
-        const int n = min((r / rw) * TN + h * 32 * BF0 + (r % rw), N - 1 - n0);
+        // GLU: half-tile row r (wave r / 32) = gate row n0/2 + r of the weight for h = 0, up row N/2 + n0/2 + r for h = 1
+        const int n = GLU ? h * (N / 2) + r : min((r / rw) * TN + h * 32 * BF0 + (r % rw), N - 1 - n0);
         ob[h][i] = (unsigned)(((int64_t)n * ldb + chunk * 8) * 2);
       }
     }
@@ -440,8 +447,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           const int c = it * 64 + lane;
           const int row = nb == 2 ? c >> 3 : c >> 2, ch = nb == 2 ? c & 7 : c & 3;
           const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
-          const int gm = mrow0 + row, gn = n0 + wn * TN + p0 * 32 + ch * 8;
+          const int gm = mrow0 + row;
+          const int gn = GLU ? (ch >> 2) * (N / 2) + n0 / 2 + wn * 32 + (ch & 3) * 8 : n0 + wn * TN + p0 * 32 + ch * 8;
           if (gm < M && gn < N) st_bf16x8(C + (int64_t)gm * ldc + gn, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if (GLU) {  // act for the 32 rows x 32 hidden units of this piece, through the same scratch (64-byte rows)
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+          for (int sc = 0; sc < 2; ++sc) {
+            const int fi = (mf / AF) * 2 * AF + (mf % AF) * 2 + sr;
+            bf16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = plm_swiglu_bf16(f2bf(acc4[fi][sc][e] * alpha), f2bf(acc4[fi][2 + sc][e] * alpha));
+            const int row = sr * 16 + l15, c = sc * 2 + (q >> 1);
+            *reinterpret_cast<bf16x4_t*>(epi + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = o;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int c = it * 64 + lane;
+          const int row = c >> 2, ch = c & 3;
+          const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
+          const int gm = mrow0 + row;
+          if (gm < M) st_bf16x8(act + (int64_t)gm * ldact + n0 / 2 + wn * 32 + ch * 8, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -1086,6 +1117,26 @@ extern "C" size_t plm_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return (size_t)p.nslabs * (size_t)(M - (int64_t)p.rfull * 256) * (size_t)N * sizeof(float);
 }
 
+// fc1 + SwiGLU in one launch (see GLU above).  Returns false when the shape does not qualify (the caller then runs the GEMM and
+// plm_swiglu_fwd separately - same bits).
+bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, uint16_t* act,
+                            int64_t ldact, int64_t M, int64_t N, int64_t K, hipStream_t s) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (K % 64 != 0 || N % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldact % 8 != 0) return false;
+  const int tm = (int)plm_cdiv(M, 256), tn = (int)(N / 256);
+  const int slots = persistent_slots();
+  const int nt_ = tm * tn;
+  const HybridArgs hyb{tm, 0, 1, nullptr};
+  hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, true>), dim3(nt_ < slots ? nt_ : slots), dim3(512), 0, s, A, lda, B, ldb, C, ldc,
+                     (int)M, (int)N, (int)K, nullptr, tm, tn, hyb, act, ldact);
+  return true;
+}
+
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
 // variant: 0 automatic | 4 / 5 / 6 the persistent kernel on 256x256 / 256x192 / 256x128 tiles (what the automatic policy picks from;
@@ -1123,7 +1174,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         const int nitems = p.rfull * tn256 + p.nchunks;
         const dim3 g2(nitems < slots ? nitems : slots);
         hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev,
-                           tm, tn256, h);
+                           tm, tn256, h, nullptr, 0);
         const int64_t nv = rem_rows * (N / 8);
         int64_t rb = plm_cdiv(nv, 256);
         if (rb > 4096) rb = 4096;
@@ -1143,10 +1194,10 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const int nt_ = tm * tn_;
   const dim3 g(nt_ < slots ? nt_ : slots);
   if (which == 0)
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, nullptr, 0);
   else if (which == 1)
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, nullptr, 0);
   else
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, nullptr, 0);
   return true;
 }

@@ -14,7 +14,7 @@ void plm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* plm_last_error_string(void) { return g_err; }
-extern "C" int plm_version(void) { return 102; }  // 102: round 2 (see include/plainlm_hip.h); 101: + plm_gemm_bf16_nt_ws, plm_gemm_nt_workspace_bytes, plm_embed_bwd_sorted, plm_embed_bwd_workspace_bytes; base-2 LSE
+extern "C" int plm_version(void) { return 103; }  // 102: round 2 (see include/plainlm_hip.h); 101: + plm_gemm_bf16_nt_ws, plm_gemm_nt_workspace_bytes, plm_embed_bwd_sorted, plm_embed_bwd_workspace_bytes; base-2 LSE
 
 // ---------------------------------------------------------------------------
 // probe: what does ds_read_b64_tr_b16 deliver?  LDS holds 0,1,2,...; lane l reads at byte 8*l.

@@ -103,6 +103,16 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// sigmoid by v_exp_f32 + v_rcp_f32 (1 ulp each): every user rounds the result to bf16, a full-precision division buys nothing.
+// Shared by the stand-alone SwiGLU kernels and the fc1 GEMM epilogue so that both produce the same bits.
+__device__ __forceinline__ float plm_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// out = bf16(bf16(silu(x)) * z) for bf16 x, z: the reference's autocast rounding order (models/components.py:55-56)
+__device__ __forceinline__ bf16_t plm_swiglu_bf16(bf16_t x, bf16_t z) {
+  const float xf = bf2f(x);
+  const bf16_t s = f2bf(xf * plm_sigmoid(xf));
+  return f2bf(bf2f(s) * bf2f(z));
+}
+
 // v_mfma_f32_16x16x32_bf16:  D[i][j] += sum_k A[i][k] B[k][j]   (same flops per cycle; a quarter of the accumulator registers
 // per instruction - measured 7-12 % more flops at the board's power limit on random operands, tools/ubench/mfma_power.hip)
 //   a: lane l holds A[i = l&15][k-slots (l>>4)*8 + 0..7]

@@ -116,6 +116,36 @@ class LinearFn(torch.autograd.Function):
     return dx, dw, None
 
 
+class FC1SwiGLUFn(torch.autograd.Function):
+  """act = silu(gate) * up with (gate | up) = x W_fc1^T (components.py:50-56): the fc1 Linear and the SwiGLU gate as one node.
+  Forward is ONE launch (activation in the GEMM epilogue, ops.fc1_swiglu); the fc1 output is kept for backward, which is the
+  SwiGLU backward followed by the plain Linear backward."""
+
+  @staticmethod
+  def forward(ctx, x, weight, lin):
+    wb, _ = lin.shadow()
+    u, act = ops.fc1_swiglu(x, wb)
+    ctx.save_for_backward(x, u)
+    ctx.lin = lin
+    return act
+
+  @staticmethod
+  def backward(ctx, dact):
+    x, u = ctx.saved_tensors
+    du = ops.swiglu_bwd(dact.contiguous(), u)
+    lin = ctx.lin
+    _, wbt = lin.shadow()
+    dx = ops.gemm_nt(du, wbt[:, :lin.out_features]) if ctx.needs_input_grad[0] else None
+    dw = None
+    if ctx.needs_input_grad[1]:
+      sink, p = lin.sink, lin.weight
+      if sink is not None and sink.active_for(p):
+        sink.defer_dw(du, x, p)
+      else:
+        dw = ops.gemm_tn(du, x)
+    return dx, dw, None
+
+
 class QKVRopeFn(torch.autograd.Function):
   """w_qkv projection + RoPE (transformer.py:42-47): returns the projection with q | k ALREADY rotated.
   Contract with AttnFn: AttnFn.backward returns the gradient w.r.t. the UN-rotated projection (the inverse

@@ -343,6 +343,23 @@ def gemm_tn_grouped(problems):
   return True
 
 
+def fc1_swiglu(x, w_fc1):
+  """fc1 of the SwiGLU MLP with the activation in the GEMM epilogue: returns (u [M, 2h] = x @ w_fc1^T as gate | up, act [M, h])."""
+  _need(x, BF16, 'fc1_swiglu.x', 2)
+  _need(w_fc1, BF16, 'fc1_swiglu.w', 2)
+  M, K = x.shape
+  N = w_fc1.shape[0]
+  if w_fc1.shape[1] != K or N % 16 != 0 or x.stride(1) != 1 or w_fc1.stride(1) != 1:
+    raise ValueError('fc1_swiglu: need x [M, K], w [2h, K] with unit inner strides and h % 8 == 0')
+  h = N // 2
+  u = torch.empty((M, N), dtype=BF16, device=x.device)
+  act = torch.empty((M, h), dtype=BF16, device=x.device)
+  with _Timed('gemm_nt', 2.0 * M * N * K):
+    _lib.check(_lib.load().plm_fc1_swiglu_bf16(_p(x), x.stride(0), _p(w_fc1), w_fc1.stride(0), _p(u), _p(act), M, h, K, _stream()),
+               'plm_fc1_swiglu_bf16')
+  return u, act
+
+
 # ---- attention ----------------------------------------------------------------------
 def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
   """Rotate the q and k column blocks of the projection output in place (once per layer)."""

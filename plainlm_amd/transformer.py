@@ -138,8 +138,8 @@ class GLU(nn.Module):
 
   def forward(self, x):
     lead = x.shape[:-1]
-    u = self.fc1(x.reshape(-1, x.shape[-1]))
-    return self.fc2(Fn.SwiGLUFn.apply(u)).view(*lead, -1)
+    act = Fn.FC1SwiGLUFn.apply(x.reshape(-1, x.shape[-1]), self.fc1.weight, self.fc1)
+    return self.fc2(act).view(*lead, -1)
 
 
 MLP_CLASSES = {'glu': GLU}
@@ -182,8 +182,7 @@ class Block(nn.Module):
       x, n1 = Fn.AddNormFn.apply(x, branch, self.attn_norm.weight, self.attn_norm)
     a = self.attn(n1, rope, doc_start, B, T)
     x, n2 = Fn.AddNormFn.apply(x, a, self.mlp_norm.weight, self.mlp_norm)
-    u = self.mlp.fc1(n2)
-    return x, self.mlp.fc2(Fn.SwiGLUFn.apply(u))
+    return x, self.mlp.fc2(Fn.FC1SwiGLUFn.apply(n2, self.mlp.fc1.weight, self.mlp.fc1))
 
 
 class Transformer(nn.Module):

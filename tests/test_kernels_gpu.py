@@ -384,6 +384,20 @@ def test_gemm_tn_grouped(ops, shapes, K):
     assert torch.equal(o, ops.gemm_tn(a, b))  # small integers: fp32 sums are exact in any order
 
 
+@pytest.mark.parametrize('M,h,K', [(2048, 2048, 768), (1000, 1024, 256), (4096, 128, 128), (300, 72, 200)])
+def test_fc1_swiglu_fused_epilogue(ops, M, h, K):
+  """fc1 + SwiGLU in one launch (gate / up half-tiles, activation in the GEMM epilogue) == GEMM followed by the stand-alone
+  kernel, bit for bit (u and act); the last two shapes take the unfused fallback of the same entry point."""
+  g = torch.Generator(device='cuda').manual_seed(M + h)
+  x = bf(torch.randn(M, K, generator=g, device='cuda'))
+  w = bf(torch.randn(2 * h, K, generator=g, device='cuda') * 0.05)
+  u, act = ops.fc1_swiglu(x, w)
+  u_ref = ops.gemm_nt(x, w)
+  assert torch.equal(u, u_ref)
+  assert torch.equal(act, ops.swiglu_fwd(u_ref))
+  close(u.float(), x.float() @ w.float().t(), 6e-3, 'fc1_swiglu u vs fp32 matmul')
+
+
 def test_gemm_linearity(ops):
   """Size-independent property at a full-size shape: G(a1+a2) == G(a1)+G(a2) for exactly-representable inputs."""
   g = torch.Generator().manual_seed(9)

@@ -105,6 +105,12 @@ def main():
           rec(f'{name} [in-step {vn}]', timeit_instep(fns, a.iters, between), flops=2.0 * m * n * k)
         del sets, big
       del A, Bm, out
+    # fc1 + SwiGLU: two launches vs the GEMM epilogue
+    A = torch.randn(M, d, device=dev).to(BF)
+    W1 = (torch.randn(2 * h, d, device=dev) * 0.02).to(BF)
+    rec('nt fc1 fwd + swiglu fwd (2 launches)', timeit(lambda: ops.swiglu_fwd(ops.gemm_nt(A, W1)), a.iters), flops=2.0 * M * 2 * h * d)
+    rec('nt fc1 fwd + swiglu (GEMM epilogue)', timeit(lambda: ops.fc1_swiglu(A, W1), a.iters), flops=2.0 * M * 2 * h * d)
+    del A, W1
     for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
                              'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}.items():
       A = torch.randn(k, m, device=dev).to(BF)

@@ -38,10 +38,14 @@ def main():
     Bm = torch.randn(n, k, device='cuda').to(BF)
     out = torch.empty(m, n, device='cuda', dtype=BF)
     torch.cuda.synchronize()
+    glu = name == 'nt fc1 fwd'  # in the step this launch carries the SwiGLU epilogue (writes act [M, h] as well)
     for _ in range(2):
-      ops.gemm_nt(A, Bm, out=out)
+      if glu:
+        ops.fc1_swiglu(A, Bm)
+      else:
+        ops.gemm_nt(A, Bm, out=out)
     torch.cuda.synchronize()
-    entry(name, 'gemm_nt', 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n), M=m, N=n, K=k)
+    entry(name + (' + swiglu (epilogue)' if glu else ''), 'gemm_nt', 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n) + (m * n if glu else 0), M=m, N=n, K=k)
     if lib.plm_gemm_nt_workspace_bytes(m, n, k) > 0:
       entry(name + ' (stream-K reduce)', 'nt_streamk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
     del A, Bm, out
