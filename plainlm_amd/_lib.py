@@ -70,6 +70,7 @@ SIGNATURES = {
   'plm_rope_qk': (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_qkv_rope_bf16': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_fc1_swiglu_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P]),
+  'plm_fc2_dx_swiglu_bwd_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P]),

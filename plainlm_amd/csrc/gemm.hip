@@ -393,6 +393,25 @@ extern "C" int plm_fc1_swiglu_bf16(const uint16_t* X, int64_t ldx, const uint16_
   return plm_swiglu_fwd(U, ACT, M, h, stream);
 }
 
+// Backward of the SwiGLU MLP's second half (models/components.py:55-57): d(act)[M, h] = dY[M, K] W2T[h, K]^T never reaches memory -
+// the epilogue of that GEMM applies the SwiGLU backward with the saved fc1 output U[M, 2h] and writes DU[M, 2h] (d(gate) | d(up)).
+// One launch when h % 256 == 0, K % 64 == 0, M >= 512; otherwise the GEMM followed by plm_swiglu_bwd (same bits; `scratch` must then
+// hold M*h bf16 values for d(act), it is not touched by the fused path and may be NULL when the shape qualifies).
+bool plm_launch_gemm_nt_glub(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* U, int64_t ldu, uint16_t* DU,
+                             int64_t lddu, int64_t M, int64_t h, int64_t K, hipStream_t s);
+extern "C" int plm_fc2_dx_swiglu_bwd_bf16(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw, const uint16_t* U, uint16_t* DU,
+                                          uint16_t* scratch, int64_t M, int64_t h, int64_t K, void* stream) {
+  PLM_REQUIRE(dY && W2T && U && DU, "plm_fc2_dx_swiglu_bwd_bf16: null pointer");
+  PLM_REQUIRE(M > 0 && h > 0 && K > 0 && h % 8 == 0, "plm_fc2_dx_swiglu_bwd_bf16: bad shape (h %% 8 == 0)");
+  if (getenv("PLM_GEMM_V1") == nullptr && plm_launch_gemm_nt_glub(dY, lddy, W2T, ldw, U, 2 * h, DU, 2 * h, M, h, K, (hipStream_t)stream)) {
+    PLM_CHECK_LAUNCH("plm_fc2_dx_swiglu_bwd_bf16");
+    return PLM_OK;
+  }
+  PLM_REQUIRE(scratch, "plm_fc2_dx_swiglu_bwd_bf16: this shape takes the two-launch path and needs the d(act) scratch");
+  if (int rc = plm_gemm_bf16_nt_ex(dY, lddy, W2T, ldw, scratch, h, M, h, K, 0, 0, nullptr, 0, stream)) return rc;
+  return plm_swiglu_bwd(scratch, U, DU, M, h, stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // TN   C[i][j] = sum_k A[k][i] B[k][j]
 // ---------------------------------------------------------------------------------------------

@@ -104,13 +104,18 @@ struct HybridArgs {
 // holds gate and up of its 32 hidden units at the same lane / register positions.  The epilogue writes C = fc1 output in its
 // ordinary [gate | up] layout (backward needs it) AND act[M, h] = bf16(bf16(silu(gate)) * up) computed from the rounded values -
 // the bits plm_swiglu_fwd produces - which removes one read of C and one launch per layer (swiglu_fwd: 69 us, 402 MB).
-template <int BM, int BN, int WM, int WN, bool HYB = false, bool GLU = false>
+// GLUB (256x256 tile only): the dX GEMM of fc2 with the SwiGLU backward in its epilogue.  The accumulators are d(act)[M, h]
+// (N = h); the epilogue rounds them to bf16 (what the stand-alone GEMM would have stored), loads gate / up of the same rows and
+// hidden units from the saved fc1 output `act` (= u [M, 2h], read-only here) and writes C = du [M, 2h]: d(gate) in columns
+// 0..h-1, d(up) in columns h..2h-1 - the bits of plm_swiglu_bwd.  d(act) never reaches memory (swiglu_bwd: 113 us, 670 MB).
+template <int BM, int BN, int WM, int WN, bool HYB = false, bool GLU = false, bool GLUB = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
                                                              HybridArgs hyb, uint16_t* __restrict__ act, int64_t ldact) {
-  static_assert(!GLU || (BM == 256 && BN == 256 && WN == 4 && !HYB), "GLU epilogue: 256x256 tiles, whole-K items");
+  static_assert(!(GLU || GLUB) || (BM == 256 && BN == 256 && WN == 4 && !HYB), "GLU epilogues: 256x256 tiles, whole-K items");
+  static_assert(!(GLU && GLUB), "one epilogue at a time");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   static_assert(WM * WN == 8 && (TN == 64 || TN == 96) && (TM == 128 || TM == 64), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // The C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
-  constexpr int NS = 2 * AF * 2 * NBF + (GLU ? 2 * AF * 2 : 0);
+  constexpr int NS = 2 * AF * 2 * NBF * (GLUB ? 2 : 1) + (GLU ? 2 * AF * 2 : 0);
   static_assert(D_P1 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
@@ -421,6 +426,49 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
+      if (GLUB) {
+        // SwiGLU backward on this 32 x 64 piece of d(act): lane (l15, q) holds, per 16 x 16 block (sr, bq, sc), row sr*16 + l15 and
+        // hidden units bq*32 + sc*16 + 4 q .. + 3 of the wave's 64
+        const uint16_t* u = act;
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr) {  // 16 rows at a time: d(gate) in scratch rows 0-15, d(up) in rows 16-31
+          const int gm_l = min(mrow0 + sr * 16 + l15, M - 1);
+          const int fi = (mf / AF) * 2 * AF + (mf % AF) * 2 + sr;
+#pragma unroll
+          for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) {
+              const int gn = n0 + wn * TN + bq * 32 + sc * 16 + 4 * q;  // N % 256 == 0: always in range
+              const bf16x4_t xv = ld_bf16x4(u + (int64_t)gm_l * ldact + gn);
+              const bf16x4_t zv = ld_bf16x4(u + (int64_t)gm_l * ldact + N + gn);
+              bf16x4_t dxo, dzo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float gf = bf2f(f2bf(acc4[fi][bq * 2 + sc][e] * alpha));  // d(act) as the GEMM would have stored it
+                const float xf = bf2f(xv[e]), zf = bf2f(zv[e]);
+                const float sig = plm_sigmoid(xf);
+                const bf16_t sv = f2bf(xf * sig);
+                const bf16_t ds = f2bf(gf * zf);
+                dzo[e] = f2bf(gf * bf2f(sv));
+                dxo[e] = f2bf(bf2f(ds) * (sig * (1.f + xf * (1.f - sig))));
+              }
+              const int c = bq * 4 + sc * 2 + (q >> 1);
+              *reinterpret_cast<bf16x4_t*>(epi + l15 * 128 + ((c ^ (l15 & 7)) << 4) + (q & 1) * 8) = dxo;
+              *reinterpret_cast<bf16x4_t*>(epi + (16 + l15) * 128 + ((c ^ (l15 & 7)) << 4) + (q & 1) * 8) = dzo;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int c = it * 64 + lane;
+            const int row = c >> 3, ch = c & 7;  // rows 0-15: d(gate), 16-31: d(up) of output row row & 15
+            const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int gm = mrow0 + sr * 16 + (row & 15);
+            if (gm < M) st_bf16x8(C + (int64_t)gm * ldc + (row >> 4) * N + n0 + wn * TN + ch * 8, v);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        continue;
+      }
       // the wave's TN columns leave in passes of up to 64 (TN = 96: 64 + 32)
 #pragma unroll
       for (int p0 = 0; p0 < NBF; p0 += 2) {
@@ -1134,6 +1182,25 @@ bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, i
   const HybridArgs hyb{tm, 0, 1, nullptr};
   hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, true>), dim3(nt_ < slots ? nt_ : slots), dim3(512), 0, s, A, lda, B, ldb, C, ldc,
                      (int)M, (int)N, (int)K, nullptr, tm, tn, hyb, act, ldact);
+  return true;
+}
+
+// dX of fc2 + SwiGLU backward in one launch (see GLUB above): DU[M, 2h] from dY[M, K] , W2^T[h, K] and the saved fc1 output U[M, 2h].
+bool plm_launch_gemm_nt_glub(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* U, int64_t ldu, uint16_t* DU,
+                             int64_t lddu, int64_t M, int64_t h, int64_t K, hipStream_t s) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (K % 64 != 0 || h % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldu % 4 != 0 || lddu % 8 != 0) return false;
+  const int tm = (int)plm_cdiv(M, 256), tn = (int)(h / 256);
+  const int slots = persistent_slots();
+  const int nt_ = tm * tn;
+  const HybridArgs hyb{tm, 0, 1, nullptr};
+  hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), dim3(nt_ < slots ? nt_ : slots), dim3(512), 0, s, A, lda, B, ldb, DU,
+                     lddu, (int)M, (int)h, (int)K, nullptr, tm, tn, hyb, const_cast<uint16_t*>(U), ldu);
   return true;
 }
 

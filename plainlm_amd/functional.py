@@ -116,34 +116,44 @@ class LinearFn(torch.autograd.Function):
     return dx, dw, None
 
 
-class FC1SwiGLUFn(torch.autograd.Function):
-  """act = silu(gate) * up with (gate | up) = x W_fc1^T (components.py:50-56): the fc1 Linear and the SwiGLU gate as one node.
-  Forward is ONE launch (activation in the GEMM epilogue, ops.fc1_swiglu); the fc1 output is kept for backward, which is the
-  SwiGLU backward followed by the plain Linear backward."""
+class SwiGLUMLPFn(torch.autograd.Function):
+  """y = fc2(silu(gate) * up) with (gate | up) = x W_fc1^T (components.py:50-57): the whole MLP as one autograd node, so that both
+  activations live in GEMM epilogues.  Forward: fc1 with the SwiGLU gate in its epilogue (ops.fc1_swiglu), then fc2.  Backward: the
+  dX GEMM of fc2 with the SwiGLU backward in ITS epilogue (ops.fc2_dx_swiglu_bwd: d(act) never reaches memory), then the plain
+  Linear backward of fc1.  Every intermediate carries the bits of the unfused chain (Linear -> SwiGLU -> Linear)."""
 
   @staticmethod
-  def forward(ctx, x, weight, lin):
-    wb, _ = lin.shadow()
-    u, act = ops.fc1_swiglu(x, wb)
-    ctx.save_for_backward(x, u)
-    ctx.lin = lin
-    return act
+  def forward(ctx, x, w1, w2, fc1, fc2):
+    w1b, _ = fc1.shadow()
+    w2b, _ = fc2.shadow()
+    u, act = ops.fc1_swiglu(x, w1b)
+    ctx.save_for_backward(x, u, act)
+    ctx.fc1, ctx.fc2 = fc1, fc2
+    return ops.gemm_nt(act, w2b)
 
   @staticmethod
-  def backward(ctx, dact):
-    x, u = ctx.saved_tensors
-    du = ops.swiglu_bwd(dact.contiguous(), u)
-    lin = ctx.lin
-    _, wbt = lin.shadow()
-    dx = ops.gemm_nt(du, wbt[:, :lin.out_features]) if ctx.needs_input_grad[0] else None
-    dw = None
+  def backward(ctx, dy):
+    x, u, act = ctx.saved_tensors
+    fc1, fc2 = ctx.fc1, ctx.fc2
+    dy = dy.contiguous()
+    _, w1t = fc1.shadow()
+    _, w2t = fc2.shadow()
+    du = ops.fc2_dx_swiglu_bwd(dy, w2t[:, :fc2.out_features], u)
+    dw2 = dw1 = None
+    if ctx.needs_input_grad[2]:
+      sink, p = fc2.sink, fc2.weight
+      if sink is not None and sink.active_for(p):
+        sink.defer_dw(dy, act, p)
+      else:
+        dw2 = ops.gemm_tn(dy, act)
+    dx = ops.gemm_nt(du, w1t[:, :fc1.out_features]) if ctx.needs_input_grad[0] else None
     if ctx.needs_input_grad[1]:
-      sink, p = lin.sink, lin.weight
+      sink, p = fc1.sink, fc1.weight
       if sink is not None and sink.active_for(p):
         sink.defer_dw(du, x, p)
       else:
-        dw = ops.gemm_tn(du, x)
-    return dx, dw, None
+        dw1 = ops.gemm_tn(du, x)
+    return dx, dw1, dw2, None, None
 
 
 class QKVRopeFn(torch.autograd.Function):

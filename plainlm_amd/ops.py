@@ -360,6 +360,25 @@ def fc1_swiglu(x, w_fc1):
   return u, act
 
 
+def fc2_dx_swiglu_bwd(dy, w2t, u):
+  """du [M, 2h] = swiglu_bwd(dy @ w2t^T, u): the dX GEMM of fc2 (w2t = bf16 W_fc2^T [h, K(+pad)]) with the SwiGLU backward in its
+  epilogue; d(act) is never stored for qualifying shapes."""
+  _need(dy, BF16, 'fc2_dx_swiglu_bwd.dy', 2)
+  _need(w2t, BF16, 'fc2_dx_swiglu_bwd.w2t', 2)
+  _need(u, BF16, 'fc2_dx_swiglu_bwd.u', 2)
+  M, K = dy.shape
+  h = w2t.shape[0]
+  if w2t.shape[1] != K or u.shape != (M, 2 * h) or not u.is_contiguous() or dy.stride(1) != 1 or w2t.stride(1) != 1:
+    raise ValueError('fc2_dx_swiglu_bwd: need dy [M, K], w2t [h, K], contiguous u [M, 2h]')
+  du = torch.empty((M, 2 * h), dtype=BF16, device=dy.device)
+  fused = h % 256 == 0 and K % 64 == 0 and M >= 512
+  scratch = None if fused else torch.empty((M, h), dtype=BF16, device=dy.device)
+  with _Timed('gemm_nt', 2.0 * M * h * K):
+    _lib.check(_lib.load().plm_fc2_dx_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w2t), w2t.stride(0), _p(u), _p(du), _p(scratch), M, h, K,
+                                                      _stream()), 'plm_fc2_dx_swiglu_bwd_bf16')
+  return du
+
+
 # ---- attention ----------------------------------------------------------------------
 def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
   """Rotate the q and k column blocks of the projection output in place (once per layer)."""

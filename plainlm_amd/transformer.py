@@ -138,8 +138,8 @@ class GLU(nn.Module):
 
   def forward(self, x):
     lead = x.shape[:-1]
-    act = Fn.FC1SwiGLUFn.apply(x.reshape(-1, x.shape[-1]), self.fc1.weight, self.fc1)
-    return self.fc2(act).view(*lead, -1)
+    y = Fn.SwiGLUMLPFn.apply(x.reshape(-1, x.shape[-1]), self.fc1.weight, self.fc2.weight, self.fc1, self.fc2)
+    return y.view(*lead, -1)
 
 
 MLP_CLASSES = {'glu': GLU}
@@ -182,7 +182,7 @@ class Block(nn.Module):
       x, n1 = Fn.AddNormFn.apply(x, branch, self.attn_norm.weight, self.attn_norm)
     a = self.attn(n1, rope, doc_start, B, T)
     x, n2 = Fn.AddNormFn.apply(x, a, self.mlp_norm.weight, self.mlp_norm)
-    return x, self.mlp.fc2(Fn.FC1SwiGLUFn.apply(n2, self.mlp.fc1.weight, self.mlp.fc1))
+    return x, Fn.SwiGLUMLPFn.apply(n2, self.mlp.fc1.weight, self.mlp.fc2.weight, self.mlp.fc1, self.mlp.fc2)
 
 
 class Transformer(nn.Module):

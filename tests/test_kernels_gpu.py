@@ -398,6 +398,18 @@ def test_fc1_swiglu_fused_epilogue(ops, M, h, K):
   close(u.float(), x.float() @ w.float().t(), 6e-3, 'fc1_swiglu u vs fp32 matmul')
 
 
+@pytest.mark.parametrize('M,h,K', [(2048, 2048, 768), (1000, 512, 256), (4096, 128, 128), (300, 72, 200)])
+def test_fc2_dx_swiglu_bwd_fused_epilogue(ops, M, h, K):
+  """dX of fc2 + SwiGLU backward in one launch == GEMM followed by the stand-alone kernel, bit for bit; the last two shapes take
+  the two-launch fallback of the same entry point."""
+  g = torch.Generator(device='cuda').manual_seed(M + 3 * h)
+  dy = bf(torch.randn(M, K, generator=g, device='cuda'))
+  w2t = bf(torch.randn(h, K, generator=g, device='cuda') * 0.05)
+  u = bf(torch.randn(M, 2 * h, generator=g, device='cuda'))
+  du = ops.fc2_dx_swiglu_bwd(dy, w2t, u)
+  assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(dy, w2t), u))
+
+
 def test_gemm_linearity(ops):
   """Size-independent property at a full-size shape: G(a1+a2) == G(a1)+G(a2) for exactly-representable inputs."""
   g = torch.Generator().manual_seed(9)

@@ -111,6 +111,12 @@ def main():
     rec('nt fc1 fwd + swiglu fwd (2 launches)', timeit(lambda: ops.swiglu_fwd(ops.gemm_nt(A, W1)), a.iters), flops=2.0 * M * 2 * h * d)
     rec('nt fc1 fwd + swiglu (GEMM epilogue)', timeit(lambda: ops.fc1_swiglu(A, W1), a.iters), flops=2.0 * M * 2 * h * d)
     del A, W1
+    dYm = torch.randn(M, d, device=dev).to(BF)
+    W2T = (torch.randn(h, d, device=dev) * 0.02).to(BF)
+    Um = torch.randn(M, 2 * h, device=dev).to(BF)
+    rec('nt dX fc2 + swiglu bwd (2 launches)', timeit(lambda: ops.swiglu_bwd(ops.gemm_nt(dYm, W2T), Um), a.iters), flops=2.0 * M * h * d)
+    rec('nt dX fc2 + swiglu bwd (GEMM epilogue)', timeit(lambda: ops.fc2_dx_swiglu_bwd(dYm, W2T, Um), a.iters), flops=2.0 * M * h * d)
+    del dYm, W2T, Um
     for name, (m, n, k) in {'tn dW qkv': (3 * d, d, M), 'tn dW out': (d, d, M), 'tn dW fc1': (2 * h, d, M),
                              'tn dW fc2': (d, h, M), 'tn dW head': (V, d, M)}.items():
       A = torch.randn(k, m, device=dev).to(BF)

@@ -38,14 +38,20 @@ def main():
     Bm = torch.randn(n, k, device='cuda').to(BF)
     out = torch.empty(m, n, device='cuda', dtype=BF)
     torch.cuda.synchronize()
-    glu = name == 'nt fc1 fwd'  # in the step this launch carries the SwiGLU epilogue (writes act [M, h] as well)
+    glu = name == 'nt fc1 fwd'   # in the step this launch carries the SwiGLU epilogue (writes act [M, h] as well)
+    glub = name == 'nt dX fc2'   # ... and this one the SwiGLU backward (reads u [M, 2h], writes du [M, 2h] instead of d(act) [M, h])
+    Um = torch.randn(m, 2 * n, device='cuda').to(BF) if glub else None
     for _ in range(2):
       if glu:
         ops.fc1_swiglu(A, Bm)
+      elif glub:
+        ops.fc2_dx_swiglu_bwd(A, Bm, Um)
       else:
         ops.gemm_nt(A, Bm, out=out)
     torch.cuda.synchronize()
-    entry(name + (' + swiglu (epilogue)' if glu else ''), 'gemm_nt', 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n) + (m * n if glu else 0), M=m, N=n, K=k)
+    alg = 2.0 * (m * k + n * k + m * n) + (m * n if glu else 0) + (2.0 * 3 * m * n if glub else 0)
+    entry(name + (' + swiglu (epilogue)' if glu else ' + swiglu bwd (epilogue)' if glub else ''), 'gemm_nt', 2.0 * m * n * k, alg, M=m, N=n, K=k)
+    del Um
     if lib.plm_gemm_nt_workspace_bytes(m, n, k) > 0:
       entry(name + ' (stream-K reduce)', 'nt_streamk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
     del A, Bm, out
