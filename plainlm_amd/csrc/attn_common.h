@@ -8,19 +8,6 @@
 // raw v_exp_f32: arguments here are <= 0 (or -inf), so no denormal-range fix-up is needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// interleaved-pair rotation of 8 consecutive head dims (4 pairs); sgn = +1 forward, -1 inverse (gradient)
-__device__ __forceinline__ bf16x8_t rope8(bf16x8_t v, f32x4_t c, f32x4_t s, float sgn) {
-  bf16x8_t o;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float a = bf2f(v[2 * p]), b = bf2f(v[2 * p + 1]);
-    const float sn = s[p] * sgn;
-    o[2 * p] = f2bf(a * c[p] - b * sn);
-    o[2 * p + 1] = f2bf(b * c[p] + a * sn);
-  }
-  return o;
-}
-
 // ---------------------------------------------------------------------------------------------
 // LDS image of a [rows][64 d] bf16 tile: row-major, 128-byte rows (so one LDS-DMA wave-instruction =
 // 8 whole rows = 8 fully used 128-byte global segments).  Inside row r (bits b0..b3) the logical 16-byte

@@ -360,9 +360,12 @@ extern "C" int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* 
   return plm_gemm_bf16_nt_ws(A, lda, B, ldb, C, ldc, M, N, K, c_dtype, accumulate, alpha_dev, 0, nullptr, 0, stream);
 }
 
-// w_qkv projection with RoPE: qkv[M, 3*nh*hd] = x W^T, then the q | k column blocks are rotated in place (row m = position
-// m % T) by the one-pass plm_rope_qk kernel.  (Round 1 also had the rotation in the GEMM epilogue: the epilogue is not
-// overlapped with MFMA work and its table loads cost 58 us per call against 31 us for the separate pass, run 23 - removed.)
+// w_qkv projection with RoPE: qkv[M, 3*nh*hd] = x W^T with the q | k column blocks rotated (row m = position m % T) in the GEMM
+// epilogue: the 16-byte chunks are rotated on their way from the transposition scratch to memory, one 16-byte table read per
+// table and chunk (round 1 rotated accumulator fragments - per-lane table gathers, 58 us per call - and lost to the 31 us
+// stand-alone pass, which remains the fallback: same bits).
+bool plm_launch_gemm_nt_rope(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M, int64_t N,
+                             int64_t K, const float* rcos, const float* rsin, int64_t T, int64_t rope_cols, hipStream_t s);
 extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* QKV, int64_t ldq, int64_t M,
                                  int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                                  void* stream) {
@@ -370,6 +373,11 @@ extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t*
   PLM_REQUIRE(hd == 64 && B > 0 && T > 0 && nh > 0 && M == B * T, "plm_qkv_rope_bf16: bad shape (hd must be 64, M == B*T)");
   const int64_t N = 3 * nh * hd;
   PLM_REQUIRE(ldq == N, "plm_qkv_rope_bf16: needs a dense output (ldq == 3*nh*hd)");
+  if (getenv("PLM_GEMM_V1") == nullptr &&
+      plm_launch_gemm_nt_rope(X, ldx, W, ldw, QKV, ldq, M, N, K, rope_cos, rope_sin, T, 2 * nh * hd, (hipStream_t)stream)) {
+    PLM_CHECK_LAUNCH("plm_qkv_rope_bf16");
+    return PLM_OK;
+  }
   if (int rc = plm_gemm_bf16_nt_ex(X, ldx, W, ldw, QKV, ldq, M, N, K, 0, 0, nullptr, 0, stream)) return rc;
   return plm_rope_qk(QKV, rope_cos, rope_sin, B, T, nh, hd, stream);
 }

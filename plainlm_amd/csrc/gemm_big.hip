@@ -108,12 +108,25 @@ struct HybridArgs {
 // (N = h); the epilogue rounds them to bf16 (what the stand-alone GEMM would have stored), loads gate / up of the same rows and
 // hidden units from the saved fc1 output `act` (= u [M, 2h], read-only here) and writes C = du [M, 2h]: d(gate) in columns
 // 0..h-1, d(up) in columns h..2h-1 - the bits of plm_swiglu_bwd.  d(act) never reaches memory (swiglu_bwd: 113 us, 670 MB).
-template <int BM, int BN, int WM, int WN, bool HYB = false, bool GLU = false, bool GLUB = false>
+// ROPE: C is the w_qkv projection [M, 3*nh*64] of M = B*T token rows; the 16-byte chunks of its q | k column blocks (columns
+// < rope_cols) are rotated on their way from the transposition scratch to memory - the same rope8() on the same bf16 values as
+// rope_qk_kernel, i.e. the same bits, without the extra pass over 2/3 of the projection (31 us, 200 MB per layer).
+struct EpiArgs {
+  uint16_t* act;        // GLU: activation output [M, N/2];  GLUB: the saved fc1 output [M, 2N] (read-only)
+  int64_t ldact;
+  const float* rcos;    // ROPE: fp32 [T, 32] tables
+  const float* rsin;
+  int T, rope_cols;
+};
+
+template <int BM, int BN, int WM, int WN, bool HYB = false, bool GLU = false, bool GLUB = false, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
                                                              uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n,
-                                                             HybridArgs hyb, uint16_t* __restrict__ act, int64_t ldact) {
+                                                             HybridArgs hyb, EpiArgs ea) {
+  uint16_t* const act = ea.act;
+  const int64_t ldact = ea.ldact;
   static_assert(!(GLU || GLUB) || (BM == 256 && BN == 256 && WN == 4 && !HYB), "GLU epilogues: 256x256 tiles, whole-K items");
   static_assert(!(GLU && GLUB), "one epilogue at a time");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -497,6 +510,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
           const int gm = mrow0 + row;
           const int gn = GLU ? (ch >> 2) * (N / 2) + n0 / 2 + wn * 32 + (ch & 3) * 8 : n0 + wn * TN + p0 * 32 + ch * 8;
+          if (ROPE) {
+            if (gm < M && gn < ea.rope_cols) {  // a q / k chunk: four pairs of head dims (gn % 64) / 2 .. + 3 at position gm % T
+              const int tab = (gm % ea.T) * 32 + ((gn & 63) >> 1);
+              st_bf16x8(C + (int64_t)gm * ldc + gn, rope8(v, *reinterpret_cast<const f32x4_t*>(ea.rcos + tab),
+                                                          *reinterpret_cast<const f32x4_t*>(ea.rsin + tab), 1.f));
+              continue;
+            }
+          }
           if (gm < M && gn < N) st_bf16x8(C + (int64_t)gm * ldc + gn, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1181,7 +1202,7 @@ bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, i
   const int nt_ = tm * tn;
   const HybridArgs hyb{tm, 0, 1, nullptr};
   hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, true>), dim3(nt_ < slots ? nt_ : slots), dim3(512), 0, s, A, lda, B, ldb, C, ldc,
-                     (int)M, (int)N, (int)K, nullptr, tm, tn, hyb, act, ldact);
+                     (int)M, (int)N, (int)K, nullptr, tm, tn, hyb, EpiArgs{act, ldact, nullptr, nullptr, 0, 0});
   return true;
 }
 
@@ -1200,7 +1221,42 @@ bool plm_launch_gemm_nt_glub(const uint16_t* A, int64_t lda, const uint16_t* B, 
   const int nt_ = tm * tn;
   const HybridArgs hyb{tm, 0, 1, nullptr};
   hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, true>), dim3(nt_ < slots ? nt_ : slots), dim3(512), 0, s, A, lda, B, ldb, DU,
-                     lddu, (int)M, (int)h, (int)K, nullptr, tm, tn, hyb, const_cast<uint16_t*>(U), ldu);
+                     lddu, (int)M, (int)h, (int)K, nullptr, tm, tn, hyb, EpiArgs{const_cast<uint16_t*>(U), ldu, nullptr, nullptr, 0, 0});
+  return true;
+}
+
+// w_qkv projection with RoPE in the epilogue (see ROPE above): the automatic tile policy of plm_launch_gemm_nt_big, no hybrid.
+bool plm_launch_gemm_nt_rope(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M, int64_t N,
+                             int64_t K, const float* rcos, const float* rsin, int64_t T, int64_t rope_cols, hipStream_t s) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (K % 64 != 0 || N % 8 != 0 || M < 512 || N < 128 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
+  const int tm = (int)plm_cdiv(M, 256);
+  const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
+  const int slots = persistent_slots();
+  const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
+  const double e192 = round_efficiency((int64_t)tm * tn192, slots) * ((double)N / (tn192 * 192.0)) * 0.94;
+  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.88;
+  if (e256 < 0.85 && e192 < 0.85 && e128 < 0.85) return false;  // badly quantised (CU reserve): the caller takes GEMM + rope pass
+  const int which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
+  const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
+  const int nt_ = tm * tn_;
+  const dim3 g(nt_ < slots ? nt_ : slots), block(512);
+  const HybridArgs hyb{tm, 0, 1, nullptr};
+  const EpiArgs ea{nullptr, 0, rcos, rsin, (int)T, (int)rope_cols};
+  if (which == 0)
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
+                       nullptr, tm, tn_, hyb, ea);
+  else if (which == 1)
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
+                       nullptr, tm, tn_, hyb, ea);
+  else
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
+                       nullptr, tm, tn_, hyb, ea);
   return true;
 }
 
@@ -1241,7 +1297,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
         const int nitems = p.rfull * tn256 + p.nchunks;
         const dim3 g2(nitems < slots ? nitems : slots);
         hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, true>), g2, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev,
-                           tm, tn256, h, nullptr, 0);
+                           tm, tn256, h, EpiArgs{});
         const int64_t nv = rem_rows * (N / 8);
         int64_t rb = plm_cdiv(nv, 256);
         if (rb > 4096) rb = 4096;
@@ -1261,10 +1317,10 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
   const int nt_ = tm * tn_;
   const dim3 g(nt_ < slots ? nt_ : slots);
   if (which == 0)
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, nullptr, 0);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
   else if (which == 1)
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, nullptr, 0);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
   else
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, nullptr, 0);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
   return true;
 }

@@ -113,6 +113,20 @@ __device__ __forceinline__ bf16_t plm_swiglu_bf16(bf16_t x, bf16_t z) {
   return f2bf(bf2f(s) * bf2f(z));
 }
 
+// RoPE on four interleaved pairs (models/embeddings.py:15-30): (a, b) -> (a cos - b sin, b cos + a sin), fp32 math, bf16 result;
+// sgn = -1 is the inverse rotation.  Shared by rope_qk_kernel, the attention backward epilogues and the w_qkv GEMM epilogue.
+__device__ __forceinline__ bf16x8_t rope8(bf16x8_t v, f32x4_t c, f32x4_t s, float sgn) {
+  bf16x8_t o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = bf2f(v[2 * p]), b = bf2f(v[2 * p + 1]);
+    const float sn = s[p] * sgn;
+    o[2 * p] = f2bf(a * c[p] - b * sn);
+    o[2 * p + 1] = f2bf(b * c[p] + a * sn);
+  }
+  return o;
+}
+
 // v_mfma_f32_16x16x32_bf16:  D[i][j] += sum_k A[i][k] B[k][j]   (same flops per cycle; a quarter of the accumulator registers
 // per instruction - measured 7-12 % more flops at the board's power limit on random operands, tools/ubench/mfma_power.hip)
 //   a: lane l holds A[i = l&15][k-slots (l>>4)*8 + 0..7]

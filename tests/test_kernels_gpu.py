@@ -498,6 +498,10 @@ def test_qkv_projection_with_rope(ops, B, T, nh, K):
   ref = torch.cat([O.rope_apply(q, cos, sin).reshape(B * T, d), O.rope_apply(k, cos, sin).reshape(B * T, d), v.reshape(B * T, d)], dim=1)
   got = ops.qkv_rope(x.cuda(), w.cuda(), cos.cuda(), sin.cuda(), B, T, nh)
   close(got.float(), ref, 8e-3, 'qkv projection + rope')
+  # the rotation in the GEMM epilogue (big shapes) and the stand-alone pass (small ones / fallback) give the same bits
+  two = ops.gemm_nt(x.cuda(), w.cuda())
+  ops.rope_qk_(two, cos.cuda(), sin.cuda(), B, T, nh)
+  assert torch.equal(got, two)
 
 
 def test_attention_softmax_rescale_branch(ops):

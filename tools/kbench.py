@@ -152,6 +152,11 @@ def main():
     ops.rope_qk_(qkv, cos, sin, B, T, nh)
     out, lse = ops.attn_fwd(qkv, B, T, nh)
     fl = 2.0 * 2 * B * nh * T * (T + 1) / 2 * 64  # causal-counted QK^T + PV
+    xq = torch.randn(M, d, device=dev).to(BF)
+    wq = (torch.randn(3 * d, d, device=dev) * 0.02).to(BF)
+    rec('nt qkv fwd + rope (2 launches)', timeit(lambda: ops.rope_qk_(ops.gemm_nt(xq, wq), cos, sin, B, T, nh), a.iters), flops=2.0 * M * 3 * d * d)
+    rec('nt qkv fwd + rope (GEMM epilogue)', timeit(lambda: ops.qkv_rope(xq, wq, cos, sin, B, T, nh), a.iters), flops=2.0 * M * 3 * d * d)
+    del xq, wq
     rec('rope qk (in place)', timeit(lambda: ops.rope_qk_(qkv, cos, sin, B, T, nh), a.iters), bytes_=8.0 * M * d)
     rec('attn fwd', timeit(lambda: ops.attn_fwd(qkv, B, T, nh), a.iters), flops=fl)
     rec('attn bwd', timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh), a.iters), flops=2.0 * fl)
