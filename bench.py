@@ -149,18 +149,29 @@ def pmc_traffic(family, config, tokens, n_layers):
   if prof.get('csrc_sha') != csrc_sha():
     return {'traffic_note': f'profiles/{os.path.basename(PMC_PROFILE)} was taken on csrc {prof.get("csrc_sha")}, this tree is '
                             f'{csrc_sha()}: not reported'}
-  rows = {r['gemm']: r for r in prof['rows']}
-  if family == 'gemm_nt':  # per layer: 4 forward + 4 dX projections (dX out has the out-fwd shape); plus lm_head fwd and dX
-    per_layer = ['nt qkv fwd', 'nt out fwd', 'nt fc1 fwd', 'nt fc2 fwd', 'nt dX qkv', 'nt out fwd', 'nt dX fc1', 'nt dX fc2']
-    once = ['nt head fwd', 'nt dX head']
-  else:
-    per_layer = ['tn dW qkv', 'tn dW out', 'tn dW fc1', 'tn dW fc2']
-    once = ['tn dW head']
-  launches = n_layers * len(per_layer) + len(once)
-  tot = lambda key: n_layers * sum(rows[g][key] for g in per_layer) + sum(rows[g][key] for g in once)
-  return {'traffic': round(tot('traffic_bytes') / launches), 'traffic_unit': 'bytes/launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, Infinity-Cache hits included)',
-          'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': f'profiles/{os.path.basename(PMC_PROFILE)}',
-          'csrc_sha': prof['csrc_sha']}
+  try:
+    rows = {r['gemm']: r for r in prof['rows']}
+
+    def row(name):  # exact name, or the row of the same launch with its fused epilogue spelled out ('nt fc1 fwd + swiglu (epilogue)')
+      hits = [r for g, r in rows.items() if g == name or g.startswith(name + ' + ') or g.startswith(name + ' (')]
+      main = [r for r in hits if 'reduce' not in r['gemm']]
+      if not main:
+        raise KeyError(name)
+      parts = [r for r in hits if 'reduce' in r['gemm']]  # split-K / stream-K reduce kernels belong to their GEMM's launch
+      return {k: main[0][k] + sum(q.get(k, 0.0) for q in parts) for k in ('traffic_bytes', 'algorithmic_bytes')}
+
+    if family == 'gemm_nt':  # per layer: 4 forward + 4 dX projections (dX out has the out-fwd shape); plus lm_head fwd and dX
+      plan = [('nt qkv fwd', n_layers), ('nt out fwd', 2 * n_layers), ('nt fc1 fwd', n_layers), ('nt fc2 fwd', n_layers),
+              ('nt dX qkv', n_layers), ('nt dX fc1', n_layers), ('nt dX fc2', n_layers), ('nt head fwd', 1), ('nt dX head', 1)]
+    else:  # the dW GEMMs of six blocks per grouped launch, plus lm_head
+      plan = [('tn dW 6 blocks', n_layers / 6.0), ('tn dW head', 1)]
+    launches = sum(c for _, c in plan)
+    tot = lambda key: sum(row(g)[key] * c for g, c in plan)
+    return {'traffic': round(tot('traffic_bytes') / launches), 'traffic_unit': 'bytes/launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, Infinity-Cache hits included)',
+            'algorithmic_bytes': round(tot('algorithmic_bytes') / launches), 'traffic_source': f'profiles/{os.path.basename(PMC_PROFILE)}',
+            'csrc_sha': prof['csrc_sha']}
+  except Exception as e:  # a profile this code cannot read must never take the benchmark down
+    return {'traffic_note': f'profiles/{os.path.basename(PMC_PROFILE)} could not be used: {type(e).__name__}: {e}'}
 
 
 def spawn_ranks(n):

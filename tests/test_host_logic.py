@@ -2,6 +2,7 @@
 mirror of the reference's module API has the right names/shapes/init/param groups, the product
 path refuses to run without a GPU, schedules and doc_start match the oracle."""
 
+import json
 import os
 from collections import namedtuple
 
@@ -160,7 +161,7 @@ def test_bucket_plan():
     assert (hi - lo) * 4 <= 4 * 700 or len(idxs) == 1
 
 
-def test_bench_metric_definition():
+def test_bench_metric_definition(monkeypatch):
   """bench.py's work model is SURVEY §8(d)'s: 797 976 576 FLOP per token for the 160M config at T = 1024 (causal-counted
   attention, fwd+bwd = 3x fwd), 2 460 745 728 for 420M at T = 2048; the committed PMC profile feeds roofline.traffic."""
   import bench
@@ -178,6 +179,13 @@ def test_bench_metric_definition():
     assert 'traffic_note' in tr
   assert bench.pmc_traffic('gemm_nt', '420m', 16384, 24) == {}
   assert len(bench.csrc_sha()) == 16 and bench.physical_cores() >= 1
+  # the launch plan bench.py sums over must match the rows of the COMMITTED profile whatever this tree's hash is (a plan / row-name
+  # mismatch once took the whole benchmark down on the GPU box, where the hashes did match)
+  if os.path.exists(bench.PMC_PROFILE):
+    monkeypatch.setattr(bench, 'csrc_sha', lambda: json.load(open(bench.PMC_PROFILE))['csrc_sha'])
+    for fam in ('gemm_nt', 'gemm_tn'):
+      tr = bench.pmc_traffic(fam, '160m', 32768, 12)
+      assert tr.get('traffic', 0) > tr.get('algorithmic_bytes', 1) > 0, (fam, tr)
 
 
 def test_bucket_plan_160m_engine_layout():
