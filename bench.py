@@ -141,7 +141,7 @@ def pmc_traffic(family, config, tokens, n_layers):
   160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the profiler on
   itself, so the figure is the profile's, averaged over the launches of one step - and ONLY when the profile was taken on
   this very tree (the profile records the sha of plainlm_amd/csrc): otherwise traffic stays null and the reason is stated."""
-  if family not in ('gemm_nt', 'gemm_tn') or config != '160m' or tokens != 32768:
+  if family not in ('gemm_nt', 'gemm_nt_fused', 'gemm_tn') or config != '160m' or tokens != 32768:
     return {}
   if not os.path.exists(PMC_PROFILE):
     return {'traffic_note': 'no PMC profile committed for this workload'}
@@ -160,9 +160,11 @@ def pmc_traffic(family, config, tokens, n_layers):
       parts = [r for r in hits if 'reduce' in r['gemm']]  # split-K / stream-K reduce kernels belong to their GEMM's launch
       return {k: main[0][k] + sum(q.get(k, 0.0) for q in parts) for k in ('traffic_bytes', 'algorithmic_bytes')}
 
-    if family == 'gemm_nt':  # per layer: 4 forward + 4 dX projections (dX out has the out-fwd shape); plus lm_head fwd and dX
-      plan = [('nt qkv fwd', n_layers), ('nt out fwd', 2 * n_layers), ('nt fc1 fwd', n_layers), ('nt fc2 fwd', n_layers),
-              ('nt dX qkv', n_layers), ('nt dX fc1', n_layers), ('nt dX fc2', n_layers), ('nt head fwd', 1), ('nt dX head', 1)]
+    if family == 'gemm_nt':  # plain launches per layer: out fwd, fc2 fwd, dX qkv, dX out (the out-fwd shape), dX fc1; plus lm_head fwd / dX
+      plan = [('nt out fwd', 2 * n_layers), ('nt fc2 fwd', n_layers), ('nt dX qkv', n_layers), ('nt dX fc1', n_layers),
+              ('nt head fwd', 1), ('nt dX head', 1)]
+    elif family == 'gemm_nt_fused':  # launches that carry an elementwise pass in their epilogue: qkv + RoPE, fc1 + SwiGLU, dX fc2 + SwiGLU bwd
+      plan = [('nt qkv fwd', n_layers), ('nt fc1 fwd', n_layers), ('nt dX fc2', n_layers)]
     else:  # the dW GEMMs of six blocks per grouped launch, plus lm_head
       plan = [('tn dW 6 blocks', n_layers / 6.0), ('tn dW head', 1)]
     launches = sum(c for _, c in plan)
@@ -363,7 +365,9 @@ def main():
     dom = max(fams, key=lambda k: fams[k]['ms_per_step'])
     out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': fams[dom]['TFLOP/s'], 'peak': PEAK_BF16_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': round(fams[dom]['TFLOP/s'] / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-                       'families': fams}
+                       'families': fams,
+                       'families_note': 'gemm_nt = plain NT GEMM launches; gemm_nt_fused = NT launches whose epilogue also does RoPE / SwiGLU / '
+                                        'SwiGLU backward (TFLOP/s counts the GEMM flops only, the time includes the fused pass)'}
     out['roofline'].update(pmc_traffic(dom, a.config, B * T, c['n_layers']))
 
     # ---- full training step (clip + AdamW) for reference, same data (untimed leg) ----

@@ -354,7 +354,7 @@ def fc1_swiglu(x, w_fc1):
   h = N // 2
   u = torch.empty((M, N), dtype=BF16, device=x.device)
   act = torch.empty((M, h), dtype=BF16, device=x.device)
-  with _Timed('gemm_nt', 2.0 * M * N * K):
+  with _Timed('gemm_nt_fused', 2.0 * M * N * K):
     _lib.check(_lib.load().plm_fc1_swiglu_bf16(_p(x), x.stride(0), _p(w_fc1), w_fc1.stride(0), _p(u), _p(act), M, h, K, _stream()),
                'plm_fc1_swiglu_bf16')
   return u, act
@@ -373,7 +373,7 @@ def fc2_dx_swiglu_bwd(dy, w2t, u):
   du = torch.empty((M, 2 * h), dtype=BF16, device=dy.device)
   fused = h % 256 == 0 and K % 64 == 0 and M >= 512
   scratch = None if fused else torch.empty((M, h), dtype=BF16, device=dy.device)
-  with _Timed('gemm_nt', 2.0 * M * h * K):
+  with _Timed('gemm_nt_fused', 2.0 * M * h * K):
     _lib.check(_lib.load().plm_fc2_dx_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w2t), w2t.stride(0), _p(u), _p(du), _p(scratch), M, h, K,
                                                       _stream()), 'plm_fc2_dx_swiglu_bwd_bf16')
   return du
@@ -400,7 +400,7 @@ def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
   N = w_qkv.shape[0]
   hd = N // (3 * nh)
   out = torch.empty((M, N), dtype=BF16, device=x.device)
-  with _Timed('gemm_nt', 2.0 * M * N * K):
+  with _Timed('gemm_nt_fused', 2.0 * M * N * K):
     _lib.check(_lib.load().plm_qkv_rope_bf16(_p(x), x.stride(0), _p(w_qkv), w_qkv.stride(0), _p(out), N, M, K, _p(rope_cos),
                                              _p(rope_sin), B, T, nh, hd, _stream()), 'plm_qkv_rope_bf16')
   return out

@@ -183,7 +183,7 @@ def test_bench_metric_definition(monkeypatch):
   # mismatch once took the whole benchmark down on the GPU box, where the hashes did match)
   if os.path.exists(bench.PMC_PROFILE):
     monkeypatch.setattr(bench, 'csrc_sha', lambda: json.load(open(bench.PMC_PROFILE))['csrc_sha'])
-    for fam in ('gemm_nt', 'gemm_tn'):
+    for fam in ('gemm_nt', 'gemm_nt_fused', 'gemm_tn'):
       tr = bench.pmc_traffic(fam, '160m', 32768, 12)
       assert tr.get('traffic', 0) > tr.get('algorithmic_bytes', 1) > 0, (fam, tr)
 

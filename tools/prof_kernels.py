@@ -40,17 +40,24 @@ def main():
     torch.cuda.synchronize()
     glu = name == 'nt fc1 fwd'   # in the step this launch carries the SwiGLU epilogue (writes act [M, h] as well)
     glub = name == 'nt dX fc2'   # ... and this one the SwiGLU backward (reads u [M, 2h], writes du [M, 2h] instead of d(act) [M, h])
+    rope = name == 'nt qkv fwd'  # ... and this one RoPE on the q | k columns (tables stay in L2: no extra algorithmic bytes)
     Um = torch.randn(m, 2 * n, device='cuda').to(BF) if glub else None
+    if rope:
+      from plainlm_amd.transformer import rope_tables
+      cos_, sin_ = (t_.cuda() for t_ in rope_tables(64, T))
     for _ in range(2):
       if glu:
         ops.fc1_swiglu(A, Bm)
       elif glub:
         ops.fc2_dx_swiglu_bwd(A, Bm, Um)
+      elif rope:
+        ops.qkv_rope(A, Bm, cos_, sin_, m // T, T, n // 192)
       else:
         ops.gemm_nt(A, Bm, out=out)
     torch.cuda.synchronize()
     alg = 2.0 * (m * k + n * k + m * n) + (m * n if glu else 0) + (2.0 * 3 * m * n if glub else 0)
-    entry(name + (' + swiglu (epilogue)' if glu else ' + swiglu bwd (epilogue)' if glub else ''), 'gemm_nt', 2.0 * m * n * k, alg, M=m, N=n, K=k)
+    suffix = ' + swiglu (epilogue)' if glu else ' + swiglu bwd (epilogue)' if glub else ' + rope (epilogue)' if rope else ''
+    entry(name + suffix, 'gemm_nt', 2.0 * m * n * k, alg, M=m, N=n, K=k)
     del Um
     if lib.plm_gemm_nt_workspace_bytes(m, n, k) > 0:
       entry(name + ' (stream-K reduce)', 'nt_streamk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
