@@ -485,7 +485,7 @@ def test_rope_qk_golden(ops, golden_dir):
   assert (qkv[:, 2 * d:] == 1).all()  # v untouched
 
 
-@pytest.mark.parametrize('B,T,nh,K', [(4, 256, 2, 128), (8, 1024, 12, 768), (3, 100, 1, 64)])
+@pytest.mark.parametrize('B,T,nh,K', [(4, 256, 2, 128), (8, 1024, 12, 768), (3, 100, 1, 64), (5, 200, 2, 128), (3, 344, 5, 64)])
 def test_qkv_projection_with_rope(ops, B, T, nh, K):
   """Projection GEMM + in-place RoPE pass (plm_qkv_rope_bf16) vs the oracle."""
   g = torch.Generator().manual_seed(B * T + nh)
