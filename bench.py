@@ -165,7 +165,7 @@ def pmc_traffic(family, config, tokens, n_layers):
               ('nt head fwd', 1), ('nt dX head', 1)]
     elif family == 'gemm_nt_fused':  # launches that carry an elementwise pass in their epilogue: qkv + RoPE, fc1 + SwiGLU, dX fc2 + SwiGLU bwd
       plan = [('nt qkv fwd', n_layers), ('nt fc1 fwd', n_layers), ('nt dX fc2', n_layers)]
-    else:  # the dW GEMMs of six blocks per grouped launch, plus lm_head
+    else:  # the dW GEMMs of all blocks as one grouped launch (the profile holds a six-block launch: counted n_layers / 6 times), plus lm_head
       plan = [('tn dW 6 blocks', n_layers / 6.0), ('tn dW head', 1)]
     launches = sum(c for _, c in plan)
     tot = lambda key: sum(row(g)[key] * c for g, c in plan)

@@ -123,7 +123,7 @@ size_t plm_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 /* Several tn problems with the SAME contraction length K (the dW GEMMs of one or more transformer blocks: engine/engine.py's
  * backward reaches them one after the other, none of them has a consumer inside backward) as ONE launch over the union of
  * their 256x256 output tiles - whole-K tiles written directly for the full rounds of the persistent grid, split-K + one
- * reduce for the remaining tiles: C_p[M_p, N_p] (+)= alpha_p * A_p[K, M_p]^T B_p[K, N_p].  count <= 24; row strides < 2^31;
+ * reduce for the remaining tiles: C_p[M_p, N_p] (+)= alpha_p * A_p[K, M_p]^T B_p[K, N_p].  count <= 48; row strides < 2^31;
  * workspace from the query below (0 = shapes cannot be grouped). */
 typedef struct plm_tn_problem {
   const uint16_t* A; int64_t lda;

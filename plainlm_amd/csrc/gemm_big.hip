@@ -572,8 +572,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 // write (C = / += alpha*acc) themselves, the remaining tiles are split over K into dense fp32 blocks
 // ws[split * n_rem + r][256][256] that tn_grouped_reduce_kernel sums into C.  The more problems a launch carries, the smaller the
 // split remainder: one block (108 tiles) is all remainder (7 pieces per tile), twelve blocks (1296 tiles) leave 16 tiles to split.
-#define PLM_TN_GROUP_MAX 24
-// (kernel arguments: 24 problems x (operands + outputs) = 1.6 KB of kernarg; hipcc 7.0 miscompiles the problem look-up from 32 up)
+#define PLM_TN_GROUP_MAX 48
+// (kernel arguments: 48 problems x (operands + outputs) = 3.2 KB of the 4 KB kernarg segment)
 struct TnGroup {
   const uint16_t* A[PLM_TN_GROUP_MAX];
   const uint16_t* B[PLM_TN_GROUP_MAX];

@@ -27,10 +27,10 @@ class GradSink:
     # Weight gradients of bias-free Linears have no consumer inside backward, so they are queued and issued several at a
     # time as ONE grouped launch (ops.gemm_tn_grouped): whole-K tiles for the full rounds of the persistent grid, split-K only
     # for the remainder.  The more problems per launch the smaller that remainder (one block = 108 tiles is all remainder:
-    # 0.50 ms; three blocks 0.41 ms per block; six blocks 0.40), but the later the gradients exist: with a gradient consumer
-    # attached (DDP buckets, `on_ready`) a group is three transformer blocks (85 MB of gradients, about one 64 MiB bucket and a
-    # half), without one it is six.
-    self.dw_group_local, self.dw_group_ddp = 24, 12
+    # 0.47 ms; three blocks 0.41 ms per block; all twelve = 1296 tiles leave 16 to split: 0.39), but the later the gradients
+    # exist: with a gradient consumer attached (DDP buckets, `on_ready`) a group is three transformer blocks (85 MB of
+    # gradients, about one 64 MiB bucket and a half), without one it is the whole model (flushed by the embedding's backward).
+    self.dw_group_local, self.dw_group_ddp = 48, 12
     self.dw_queue = []
     # RMSNorm weight gradients: the backward kernel leaves per-block partial sums; their column sums (25 launch-bound
     # kernels at the 160M size) are queued and run as ONE launch when backward reaches the embedding (flush_dw)

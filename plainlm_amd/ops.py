@@ -305,13 +305,13 @@ def gemm_tn(A, B, out=None, accumulate=False, alpha=None):
   return out
 
 
-TN_GROUP_MAX = 24  # PLM_TN_GROUP_MAX of csrc/gemm_big.hip
+TN_GROUP_MAX = 48  # PLM_TN_GROUP_MAX of csrc/gemm_big.hip
 
 
 def gemm_tn_grouped(problems):
   """Several dW-style GEMMs with the same contraction length as ONE launch over the union of their output tiles (whole-K tiles for
   the full rounds of the persistent grid, split-K + one reduce for the remainder):
-  problems = [(A[K,M] bf16, B[K,N] bf16, out[M,N] fp32, accumulate, alpha or None), ...] (at most TN_GROUP_MAX = 24);
+  problems = [(A[K,M] bf16, B[K,N] bf16, out[M,N] fp32, accumulate, alpha or None), ...] (at most TN_GROUP_MAX = 48);
   out (+)= alpha * A^T @ B for each.  Returns False when the shapes cannot be grouped (the caller then uses gemm_tn)."""
   n = len(problems)
   if n < 1 or n > TN_GROUP_MAX:

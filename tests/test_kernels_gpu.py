@@ -357,6 +357,8 @@ def test_gemm_tn(ops, M, N, K):
     ([(768, 768), (8, 8), (1000, 392)], 4096),
     # 24 problems = six 160M blocks: 648 tiles = two whole-K rounds written directly + 136 tiles split over K
     ([(768, 2048), (4096, 768), (768, 768), (2304, 768)] * 6, 2048),
+    # 48 problems = all twelve 160M blocks: 1296 tiles = five whole-K rounds + 16 tiles split over K
+    ([(768, 2048), (4096, 768), (768, 768), (2304, 768)] * 12, 1024),
     # 6 ragged problems whose 262 tiles straddle the whole-K / split boundary inside one problem
     ([(1000, 1032), (520, 264), (2304, 768), (136, 72), (3000, 1544), (4096, 776)], 1024),
 ])

@@ -137,7 +137,7 @@ def main():
     fl = sum(2.0 * m * n * M for m, n in shp)
     rec('tn dW block, 4 launches', timeit(lambda: [ops.gemm_tn(a_, b_, out=o_, accumulate=False) for a_, b_, o_ in zip(As, Bs, outs)], a.iters), flops=fl)
     rec('tn dW block, grouped (1 block = 4 problems)', timeit(lambda: ops.gemm_tn_grouped([(a_, b_, o_, False, None) for a_, b_, o_ in zip(As, Bs, outs)]), a.iters), flops=fl)
-    for nb in (3, 6):  # what the engine issues: 3 blocks per launch under DDP, 6 without a gradient consumer
+    for nb in (3, 6, 12):  # what the engine issues: 3 blocks per launch under DDP, all 12 without a gradient consumer
       outs_n = [torch.zeros(m, n, device=dev) for m, n in shp * nb]
       probs = [(a_, b_, o_, False, None) for a_, b_, o_ in zip(As * nb, Bs * nb, outs_n)]
       rec(f'tn dW, grouped x{nb} blocks (per block)', timeit(lambda: ops.gemm_tn_grouped(probs), a.iters) / nb, flops=fl)
