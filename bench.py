@@ -165,8 +165,10 @@ def pmc_traffic(family, config, tokens, n_layers):
               ('nt head fwd', 1), ('nt dX head', 1)]
     elif family == 'gemm_nt_fused':  # launches that carry an elementwise pass in their epilogue: qkv + RoPE, fc1 + SwiGLU, dX fc2 + SwiGLU bwd
       plan = [('nt qkv fwd', n_layers), ('nt fc1 fwd', n_layers), ('nt dX fc2', n_layers)]
-    else:  # the dW GEMMs of all blocks as one grouped launch (the profile holds a six-block launch: counted n_layers / 6 times), plus lm_head
-      plan = [('tn dW 6 blocks', n_layers / 6.0), ('tn dW head', 1)]
+    else:  # the dW GEMMs of the blocks as grouped launches of however many blocks the profile measured, plus lm_head
+      import re
+      nb = next(int(m.group(1)) for m in (re.match(r'tn dW (\d+) blocks', g) for g in rows) if m)
+      plan = [(f'tn dW {nb} blocks', n_layers / float(nb)), ('tn dW head', 1)]
     launches = sum(c for _, c in plan)
     tot = lambda key: sum(row(g)[key] * c for g, c in plan)
     return {'traffic': round(tot('traffic_bytes') / launches), 'traffic_unit': 'bytes/launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, Infinity-Cache hits included)',

@@ -74,9 +74,9 @@ def main():
     if lib.plm_gemm_tn_workspace_bytes(m, n, k) > 0:
       entry(name + ' (split-K reduce)', 'splitk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
     del A, Bm, out
-  # the dW GEMMs of six blocks as the engine issues them on one GPU: one grouped launch (whole-K tiles + split remainder) + one reduce
+  # the dW GEMMs of all twelve blocks as the engine issues them on one GPU: one grouped launch (whole-K tiles + split remainder) + one reduce
   gp = []
-  for _blk in range(6):
+  for _blk in range(12):
     for name in ('tn dW fc2', 'tn dW fc1', 'tn dW out', 'tn dW qkv'):
       m, n, k = TN[name]
       gp.append((torch.randn(k, m, device='cuda').to(BF), torch.randn(k, n, device='cuda').to(BF), torch.zeros(m, n, device='cuda'), False, None))
@@ -86,8 +86,8 @@ def main():
   torch.cuda.synchronize()
   fl = sum(2.0 * a.shape[1] * b.shape[1] * a.shape[0] for a, b, *_ in gp)
   alg = sum(2.0 * (a.numel() + b.numel()) + 4.0 * o.numel() for a, b, o, *_ in gp)
-  entry('tn dW 6 blocks (grouped x24)', 'gemm_tn', fl, alg, K=M)
-  entry('tn dW 6 blocks (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of='tn dW 6 blocks (grouped x24)')
+  entry('tn dW 12 blocks (grouped x48)', 'gemm_tn', fl, alg, K=M)
+  entry('tn dW 12 blocks (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of='tn dW 12 blocks (grouped x48)')
   del gp
   # attention: the step's inputs have the statistics of a freshly initialised model (projection outputs ~N(0, 0.4))
   qkv = (0.4 * torch.randn(M, 3 * d, device='cuda')).to(BF)
