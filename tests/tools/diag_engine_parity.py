@@ -13,7 +13,7 @@ from collections import namedtuple
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import cpu_ref as O  # noqa: E402
 from oracle import cpu_ref_bf16 as E  # noqa: E402

@@ -145,8 +145,8 @@ def main():
     del As, Bs, outs
 
   if want('attn'):
-    from oracle import cpu_ref as O
-    cos, sin = (t.to(dev) for t in O.rope_table(64, T))
+    from plainlm_amd.transformer import rope_tables
+    cos, sin = (t.to(dev) for t in rope_tables(64, T))
     qkv = torch.randn(M, 3 * d, device=dev).to(BF)
     dout = torch.randn(M, d, device=dev).to(BF)
     ops.rope_qk_(qkv, cos, sin, B, T, nh)

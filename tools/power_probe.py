@@ -187,9 +187,9 @@ def main():
     run_case(f'tn dW head [{kind}]', lambda: ops.gemm_tn(A, Bm, out=out, accumulate=True), 2.0 * m * n * k, a.seconds, files)
     del A, Bm, out
   # attention and an HBM-bound kernel for comparison
-  from oracle import cpu_ref as O  # rope table only (tools/, not the product path)
+  from plainlm_amd.transformer import rope_tables
   B, T, nh = 32, 1024, 12
-  cos, sin = (t.to(dev) for t in O.rope_table(64, T))
+  cos, sin = (t.to(dev) for t in rope_tables(64, T))
   for kind in ('randn', 'zeros'):
     qkv = operands(kind, M, 3 * d, dev)
     dout = operands(kind, M, d, dev)

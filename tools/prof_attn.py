@@ -2,9 +2,9 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from plainlm_amd import ops
-from oracle import cpu_ref as O
+from plainlm_amd.transformer import rope_tables
 B, T, nh, d = 32, 1024, 12, 768
-cos, sin = (t.cuda() for t in O.rope_table(64, T))
+cos, sin = (t.cuda() for t in rope_tables(64, T))
 qkv = torch.randn(B * T, 3 * d, device='cuda').to(torch.bfloat16)
 dout = torch.randn(B * T, d, device='cuda').to(torch.bfloat16)
 for _ in range(3):

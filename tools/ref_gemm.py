@@ -40,7 +40,7 @@ if len(sys.argv) > 1:
 
 # ---- attention yardstick: torch SDPA (vendor flash kernels) vs ours, causal, B=32 nh=12 T=1024 hd=64 ----
 import torch.nn.functional as F
-from oracle import cpu_ref as O
+from plainlm_amd.transformer import rope_tables
 Bq, T, nh = 32, 1024, 12
 q, k, v = (torch.randn(Bq, nh, T, 64, device='cuda', dtype=BF, requires_grad=True) for _ in range(3))
 do = torch.randn(Bq, nh, T, 64, device='cuda', dtype=BF)
@@ -49,7 +49,7 @@ def sdpa_fb():
   o = F.scaled_dot_product_attention(q, k, v, is_causal=True); o.backward(do); q.grad = k.grad = v.grad = None
 fl = 4.0 * Bq * nh * 64 * T * (T + 1) / 2
 t_f = timeit(sdpa_fwd); t_fb = timeit(sdpa_fb)
-cos, sin = (t.cuda() for t in O.rope_table(64, T))
+cos, sin = (t.cuda() for t in rope_tables(64, T))
 qkv = torch.randn(Bq * T, 3 * nh * 64, device='cuda').to(BF); dout = torch.randn(Bq * T, nh * 64, device='cuda').to(BF)
 out, lse = ops.attn_fwd(qkv, Bq, T, nh)
 o_f = timeit(lambda: ops.attn_fwd(qkv, Bq, T, nh)); o_b = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cos, sin, Bq, T, nh))
