@@ -32,8 +32,7 @@ def main():
   eng = P.TorchEngine(model, cfg, 'cuda', None, None)
   rng = np.random.default_rng(0)
   batches = [{'input_ids': torch.from_numpy(rng.integers(0, cfg.vocab_size, size=(32, 1025)))} for _ in range(4)]
-  # 24 untimed steps: a one-off 40-80 ms stall shows up around the 14th step of a process on this stack (allocator / runtime
-  # warm-up; it does not recur in 60 further steps) and used to sit inside the 20 timed ones
+  # 24 untimed steps (the allocator and the runtime settle in the first dozen)
   for i in range(24):
     eng.step(batches[i % 4])
   torch.cuda.synchronize()
