@@ -309,6 +309,14 @@ def test_gemms_with_cu_reserve(ops, monkeypatch):
   workgroups and every plan (tile choice, hybrid stream-K, TN split) is recomputed for that count.  Same answers required."""
   monkeypatch.setenv('PLM_NT_HYBRID_MIN_K', '64')
   g = torch.Generator(device='cuda').manual_seed(11)
+  M, d, h = 16384, 768, 2048
+  fx = bf(torch.randn(M, d, generator=g, device='cuda'))
+  fw1 = bf(0.05 * torch.randn(2 * h, d, generator=g, device='cuda'))
+  fw2t = bf(0.05 * torch.randn(h, d, generator=g, device='cuda'))
+  fwq = bf(0.05 * torch.randn(3 * d, d, generator=g, device='cuda'))
+  fcos, fsin = (t.cuda() for t in O.rope_table(64, 1024))
+  fu, fact = ops.fc1_swiglu(fx, fw1)  # whole chip
+  fref = (fu, fact, ops.fc2_dx_swiglu_bwd(fx, fw2t, fu), ops.qkv_rope(fx, fwq, fcos, fsin, 16, 1024, 12))
   try:
     ops.set_cu_reserve(16)
     for M, N, K in [(32768, 768, 2048), (32768, 2304, 768), (8192, 4096, 768), (32700, 1032, 1024), (4096, 50280, 768)]:
@@ -319,6 +327,20 @@ def test_gemms_with_cu_reserve(ops, monkeypatch):
       A = bf(torch.randn(K, M, generator=g, device='cuda'))
       B = bf(torch.randn(K, N, generator=g, device='cuda'))
       close(ops.gemm_tn(A, B), A.float().t() @ B.float(), 2e-5 * math.sqrt(K), f'gemm_tn with reserve {M}x{N}x{K}')
+    # the launches with fused epilogues on 240 workgroups: the bits of the same launches on the whole chip (the schedule changes,
+    # a tile's arithmetic does not)
+    u, act = ops.fc1_swiglu(fx, fw1)
+    assert torch.equal(u, fref[0]) and torch.equal(act, fref[1])
+    assert torch.equal(ops.fc2_dx_swiglu_bwd(fx, fw2t, fref[0]), fref[2])
+    assert torch.equal(ops.qkv_rope(fx, fwq, fcos, fsin, 16, 1024, 12), fref[3])
+    K = 4096
+    shapes = [(768, 2048), (4096, 768), (768, 768), (2304, 768)] * 3  # what a data-parallel run groups: three blocks
+    As = [bf(torch.randint(-3, 4, (K, m), generator=g, device='cuda').float()) for m, _ in shapes]
+    Bs = [bf(torch.randint(-3, 4, (K, n), generator=g, device='cuda').float()) for _, n in shapes]
+    outs = [torch.empty((m, n), device='cuda') for m, n in shapes]
+    assert ops.gemm_tn_grouped([(a, b, o, False, None) for a, b, o in zip(As, Bs, outs)])
+    for a, b, o in zip(As, Bs, outs):
+      assert torch.equal(o, a.float().t() @ b.float())  # small integers: exact in any summation order
   finally:
     ops.set_cu_reserve(0)
 
