@@ -184,6 +184,11 @@ class HipEngine(torch.nn.Module):
     # next call otherwise; an update computed from a NaN loss is never applied, no micro-step goes unchecked (eval() and
     # check_losses() drain).  nan_check_lag = 0 restores the reference's order exactly; larger values defer further inside a window.
     self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 1))
+    # Optional (cfg.gc_freeze: True): after the first optimizer step, move every object alive at that point (model, optimizer,
+    # autograd function classes, caches) out of the cyclic garbage collector's generations.  Python's full collections otherwise
+    # walk all of them every few dozen steps: 10-50 ms pauses of a host loop that does 7 ms of work per step.  It is a
+    # process-wide setting, hence off unless asked for.
+    self._gc_freeze_pending = bool(getattr(cfg, 'gc_freeze', False))
     self._unchecked, self._flag_pool = [], []
     if self.dtype != 'bfloat16':
       raise NotImplementedError(f"dtype '{self.dtype}': the gfx950 kernels implement the bfloat16 flow only")
@@ -251,6 +256,11 @@ class HipEngine(torch.nn.Module):
       self.optimizer.zero_grad(set_to_none=True)
       if self.scheduler:
         self.scheduler.step()
+      if self._gc_freeze_pending:
+        import gc
+        gc.collect()
+        gc.freeze()
+        self._gc_freeze_pending = False
     return loss_val
 
   def _submit_nan_flag(self, loss_val):
