@@ -21,10 +21,14 @@ def main():
   n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
   rnd = random.Random(seed)
   g = torch.Generator(device='cuda').manual_seed(seed)
-  os.environ['PLM_NT_HYBRID_MIN_K'] = '64'  # let the hybrid schedule trigger on small K too
   bad = 0
   for it in range(n):
-    kind = rnd.choice(['nt', 'nt', 'tn', 'grouped'])
+    kind = rnd.choice(['nt', 'nt', 'tn', 'grouped', 'glu', 'glub', 'rope'])
+    # let the hybrid (split-K) schedule trigger on small K too - except where bit-equality with a whole-K launch is the test
+    if kind in ('glu', 'glub', 'rope'):
+      os.environ.pop('PLM_NT_HYBRID_MIN_K', None)
+    else:
+      os.environ['PLM_NT_HYBRID_MIN_K'] = '64'
     if kind == 'nt':
       M = rnd.choice([8, 136, 256, 1000, 4096, 8192, 20480, 32768, 33000]) + 8 * rnd.randint(0, 3)
       N = rnd.choice([8, 72, 256, 392, 768, 1032, 2304, 4096]) + 8 * rnd.randint(0, 2)
@@ -46,8 +50,38 @@ def main():
       ops.gemm_tn(A, B, out=out, accumulate=acc)
       e = relerr(out, ref + (1.5 if acc else 0.0))
       tol = 2e-5 * math.sqrt(K) + 1e-6
+    elif kind in ('glu', 'glub', 'rope'):
+      # launches with fused epilogues must give the bits of GEMM + stand-alone kernel (shapes on both sides of the fused / fallback line)
+      M = rnd.choice([300, 512, 1000, 4096, 8200, 32768])
+      K = rnd.choice([64, 128, 576, 768, 1024]) + rnd.choice([0, 0, 8])
+      if kind == 'rope':
+        T = rnd.choice([100, 256, 344, 1024])
+        Bt = max(1, M // T)
+        M, nh = Bt * T, rnd.choice([1, 2, 5, 12])
+        N = 3 * nh * 64
+        from plainlm_amd.transformer import rope_tables
+        cos, sin = (t.cuda() for t in rope_tables(64, T))
+        x = torch.randn(M, K, generator=g, device='cuda').to(BF)
+        w = (0.05 * torch.randn(N, K, generator=g, device='cuda')).to(BF)
+        two = ops.gemm_nt(x, w)
+        ops.rope_qk_(two, cos, sin, Bt, T, nh)
+        e = 0.0 if torch.equal(ops.qkv_rope(x, w, cos, sin, Bt, T, nh), two) else 1.0
+      else:
+        h = rnd.choice([72, 128, 256, 1024, 2048, 2816])
+        N = 2 * h
+        x = torch.randn(M, K, generator=g, device='cuda').to(BF)
+        if kind == 'glu':
+          w = (0.05 * torch.randn(2 * h, K, generator=g, device='cuda')).to(BF)
+          u, act = ops.fc1_swiglu(x, w)
+          u2 = ops.gemm_nt(x, w)
+          e = 0.0 if torch.equal(u, u2) and torch.equal(act, ops.swiglu_fwd(u2)) else 1.0
+        else:
+          w = (0.05 * torch.randn(h, K, generator=g, device='cuda')).to(BF)
+          u = torch.randn(M, 2 * h, generator=g, device='cuda').to(BF)
+          e = 0.0 if torch.equal(ops.fc2_dx_swiglu_bwd(x, w, u), ops.swiglu_bwd(ops.gemm_nt(x, w), u)) else 1.0
+      tol = 0.0
     else:
-      cnt = rnd.randint(1, 8)
+      cnt = rnd.choice([1, 3, 8, 17, 31, 48])
       K = rnd.choice([64, 512, 4096, 32768])
       shp = [(rnd.choice([8, 136, 768, 2304, 4096]) + 8 * rnd.randint(0, 2), rnd.choice([8, 264, 768, 2048]) + 8 * rnd.randint(0, 2)) for _ in range(cnt)]
       As = [torch.randn(K, m, generator=g, device='cuda').to(BF) for m, _ in shp]
