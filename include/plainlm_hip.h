@@ -166,7 +166,8 @@ int plm_fc1_swiglu_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64
                         int64_t h, int64_t K, void* stream);
 /* dX of fc2 with the SwiGLU backward in the GEMM epilogue: DU[M, 2h] = swiglu_bwd(dY[M,K] W2T[h,K]^T, U[M,2h]) where W2T is the
  * transposed bf16 copy of fc2's weight and U the saved fc1 output; d(act) is never stored.  One launch when h % 256 == 0,
- * K % 64 == 0, M >= 512; otherwise GEMM + plm_swiglu_bwd through `scratch` (M*h bf16; may be NULL for qualifying shapes). */
+ * K % 64 == 0, M >= 512; otherwise GEMM + plm_swiglu_bwd through `scratch` (M*h bf16).  With scratch == NULL the call either takes the
+ * one-launch path or returns PLM_E_WORKSPACE without launching anything. */
 int plm_fc2_dx_swiglu_bwd_bf16(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw, const uint16_t* U, uint16_t* DU,
                                uint16_t* scratch, int64_t M, int64_t h, int64_t K, void* stream);
 int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,

@@ -415,7 +415,10 @@ extern "C" int plm_fc2_dx_swiglu_bwd_bf16(const uint16_t* dY, int64_t lddy, cons
     PLM_CHECK_LAUNCH("plm_fc2_dx_swiglu_bwd_bf16");
     return PLM_OK;
   }
-  PLM_REQUIRE(scratch, "plm_fc2_dx_swiglu_bwd_bf16: this shape takes the two-launch path and needs the d(act) scratch");
+  if (!scratch) {  // not an error of the shape: the caller retries with the buffer
+    plm_set_error("plm_fc2_dx_swiglu_bwd_bf16: this shape (or PLM_GEMM_V1) takes the two-launch path and needs the M*h bf16 d(act) scratch");
+    return PLM_E_WORKSPACE;
+  }
   if (int rc = plm_gemm_bf16_nt_ex(dY, lddy, W2T, ldw, scratch, h, M, h, K, 0, 0, nullptr, 0, stream)) return rc;
   return plm_swiglu_bwd(scratch, U, DU, M, h, stream);
 }

@@ -371,11 +371,15 @@ def fc2_dx_swiglu_bwd(dy, w2t, u):
   if w2t.shape[1] != K or u.shape != (M, 2 * h) or not u.is_contiguous() or dy.stride(1) != 1 or w2t.stride(1) != 1:
     raise ValueError('fc2_dx_swiglu_bwd: need dy [M, K], w2t [h, K], contiguous u [M, 2h]')
   du = torch.empty((M, 2 * h), dtype=BF16, device=dy.device)
-  fused = h % 256 == 0 and K % 64 == 0 and M >= 512
-  scratch = None if fused else torch.empty((M, h), dtype=BF16, device=dy.device)
+  lib = _lib.load()
   with _Timed('gemm_nt_fused', 2.0 * M * h * K):
-    _lib.check(_lib.load().plm_fc2_dx_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w2t), w2t.stride(0), _p(u), _p(du), _p(scratch), M, h, K,
-                                                      _stream()), 'plm_fc2_dx_swiglu_bwd_bf16')
+    # first without the d(act) scratch: the one-launch path never touches it; the library answers PLM_E_WORKSPACE (-4) when this
+    # shape takes the two-launch path, and only then is the buffer allocated
+    rc = lib.plm_fc2_dx_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w2t), w2t.stride(0), _p(u), _p(du), _p(None), M, h, K, _stream())
+    if rc == -4:
+      scratch = torch.empty((M, h), dtype=BF16, device=dy.device)
+      rc = lib.plm_fc2_dx_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w2t), w2t.stride(0), _p(u), _p(du), _p(scratch), M, h, K, _stream())
+    _lib.check(rc, 'plm_fc2_dx_swiglu_bwd_bf16')
   return du
 
 

@@ -434,6 +434,27 @@ def test_fc2_dx_swiglu_bwd_fused_epilogue(ops, M, h, K):
   assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(dy, w2t), u))
 
 
+def test_fused_entry_points_fall_back_under_gemm_v1(ops, monkeypatch):
+  """PLM_GEMM_V1=1 forces the register-staged 128x128 GEMMs: the three entry points with fused epilogues must then take their
+  two-launch paths (the backward one asks for its d(act) scratch with PLM_E_WORKSPACE and gets it) and still be right."""
+  monkeypatch.setenv('PLM_GEMM_V1', '1')
+  g = torch.Generator(device='cuda').manual_seed(5)
+  M, d, h = 1024, 256, 512
+  x = bf(torch.randn(M, d, generator=g, device='cuda'))
+  w1 = bf(0.05 * torch.randn(2 * h, d, generator=g, device='cuda'))
+  u, act = ops.fc1_swiglu(x, w1)
+  close(u.float(), x.float() @ w1.float().t(), 6e-3, 'fc1 (v1)')
+  assert torch.equal(act, ops.swiglu_fwd(u))
+  w2t = bf(0.05 * torch.randn(h, d, generator=g, device='cuda'))
+  du = ops.fc2_dx_swiglu_bwd(x, w2t, u)
+  assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(x, w2t), u))
+  cos, sin = (t.cuda() for t in O.rope_table(64, 256))
+  wq = bf(0.05 * torch.randn(3 * 128, d, generator=g, device='cuda'))
+  two = ops.gemm_nt(x, wq)
+  ops.rope_qk_(two, cos, sin, 4, 256, 2)
+  assert torch.equal(ops.qkv_rope(x, wq, cos, sin, 4, 256, 2), two)
+
+
 def test_gemm_linearity(ops):
   """Size-independent property at a full-size shape: G(a1+a2) == G(a1)+G(a2) for exactly-representable inputs."""
   g = torch.Generator().manual_seed(9)
