@@ -206,3 +206,39 @@ def test_bucket_plan_160m_engine_layout():
   assert b[-1][2] == list(range(n_norm + 1))                       # norms + embed_tokens: the tail
   assert all((hi - lo) * 4 <= (64 << 20) for lo, hi, _ in b[1:-1])
   assert sum(hi - lo for lo, hi, _ in b) == off and len(b) <= 12
+
+
+def test_gradsink_groups_weight_gradient_gemms(monkeypatch):
+  """GradSink's queueing policy (host logic only; the launches are faked): without a gradient consumer the dW GEMMs of the whole
+  model go out as ONE grouped launch (48 problems at the 160M depth) when backward reaches the embedding; with one (DDP buckets)
+  a group is three transformer blocks = 12 problems; accumulate flags follow first-write-in-window; every parameter is reported
+  ready exactly once per flush, after its launch."""
+  from plainlm_amd import functional as Fn
+  calls, ready = [], []
+  monkeypatch.setattr(Fn.ops, 'gemm_tn_grouped', lambda probs: calls.append([(id(o), acc) for _, _, o, acc, _ in probs]) or True)
+  monkeypatch.setattr(Fn.ops, 'gemm_tn', lambda *a, **k: calls.append(('single', k.get('accumulate'))))
+  monkeypatch.setattr(Fn.ops, 'colsum_multi', lambda items: None)
+
+  class FakeParam:
+    def __init__(self):
+      self.main_grad = object()
+
+  for consumer, group in ((None, 48), (lambda p: ready.append(p), 12)):
+    sink = Fn.GradSink()
+    sink.on_ready = consumer
+    calls.clear()
+    ready.clear()
+    params = [FakeParam() for _ in range(48)]
+    sink.begin_window()
+    for i, p in enumerate(params):  # 12 blocks x 4 projections, as backward reaches them
+      sink.defer_dw('dy', 'x', p)
+      assert len(calls) == (i + 1) // group
+    sink.flush_dw()
+    assert [len(c) for c in calls] == [group] * (48 // group)
+    assert all(acc is False for c in calls for _, acc in c)          # first write in the window overwrites
+    if consumer is not None:
+      assert ready == params                                        # one report per parameter, in launch order
+    calls.clear()
+    sink.defer_dw('dy', 'x', params[0])                             # second micro-step of the window: accumulate
+    sink.flush_dw()
+    assert calls == [('single', True)]
