@@ -7,6 +7,9 @@ stream, ``finish()`` joins, FlatAdamW clips and steps.  Invariants (SURVEY.md se
   (i)   2 ranks x accumulation 2 on the shards r::2  ==  1 rank x accumulation 4 on all micro-batches,
   (ii)  both ranks hold bit-identical parameters after every optimizer step,
   (iii) many small buckets == one bucket (bitwise: a 2-rank mean is order-independent),
+  (iv)  the 2-rank losses and the 1-rank x accumulation-4 losses are within 1e-4 of the CPU ORACLE engine
+        (oracle.cpu_ref.OracleEngine, accumulation 4) on the same 8 micro-batches - the HIP path is not only
+        compared with itself,
 and non-final accumulation micro-steps do not communicate.  Also run with tied embeddings (the shared weight's
 gradient has two writers per backward)."""
 
@@ -118,7 +121,26 @@ def test_two_rank_engine_equals_accumulation(tmp_path, tied):
     want = [single[k * world + r] for k in range(4)]
     assert got[:2] == want[:2], (r, got, want)
     np.testing.assert_allclose(got[2:], want[2:], rtol=2e-5)
+  # (iv) against the CPU oracle engine (fp32 restatement of engine/engine.py:93-141): accumulation 4 over the same 8
+  # micro-batches in the single-rank order.  North-star tolerance 1e-4 relative on every micro-step, before and after
+  # the optimizer update, for the 1-rank and for the 2-rank run.
+  from oracle import cpu_ref as O
+  ocfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2, tie_embeddings=tied)
+  ow = {k: v for k, v in _weights(tied).items() if not (tied and k == 'lm_head.weight')}
+  orc = O.OracleEngine(ow, ocfg, lr=3e-3, weight_decay=0.1, beta1=0.9, beta2=0.95, grad_clip=1.0, accum=4, steps_budget=8,
+                       warmup_steps=2, lr_start=1e-3)
+  want_o = [orc.step({'input_ids': tok[i]}).item() for i in range(8)]
+  np.testing.assert_allclose(single, want_o, rtol=1e-4)
+  for r in range(world):
+    np.testing.assert_allclose(many[r]['losses'], [want_o[k * world + r] for k in range(4)], rtol=1e-4)
+  # ... and the parameters after the two optimizer steps: AdamW moves a weight by ~lr per step whatever its gradient, so
+  # the yardstick is lr (same bounds as test_engine_loss_sequence_vs_reference)
   lr = 3e-3
+  for n, p in many[0]['params'].items():
+    if n not in orc.params:
+      continue
+    frac_off = ((p - orc.params[n]).abs() > 0.5 * lr).float().mean().item()
+    assert frac_off < 0.01, (n, frac_off)
   for n, p in eng.model.named_parameters():
     diff = (many[0]['params'][n] - p.detach().cpu()).abs()
     # (a + b) / 2 across ranks vs sequential accumulation differ in the last fp32 bits of the window's gradient.  After the
@@ -131,3 +153,30 @@ def test_two_rank_engine_equals_accumulation(tmp_path, tied):
     assert (diff > 0.02 * lr).float().mean().item() < 0.01, n
     assert diff.pow(2).mean().sqrt().item() < 0.02 * lr, n
     assert diff.max().item() <= 2.5 * 2 * lr, n
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_device():
+  """`python bench.py --gpus 2 --single-device`: the parent spawns the two rank processes itself (bench.py::spawn_ranks, the
+  launch the driver uses when no torch.distributed.run is around), both ranks run the real step on cuda:0 and exchange
+  gradients through the reducer over gloo.  Exercises rank discovery, the control-plane group, the row sharding r::W, the
+  barrier / max-over-ranks timing and the one-JSON-line contract every round (engine/engine.py:64-65,104-105,
+  cluster/multi_gpu/slurm.sh:23-26).  The printed rate is a plumbing check, and the line says so."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--single-device', '--steps', '2', '--warmup', '1',
+                      '--no-extras'], cwd=root, env=env, capture_output=True, text=True, timeout=840)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+  out = json.loads(lines[0])
+  assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
+  assert out['comm']['ranks'] == 2 and out['comm']['buckets'] >= 2
+  assert out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
+  assert 'PLUMBING CHECK ONLY' in out['data']
+  assert out['value'] > 0 and np.isfinite(out['loss']) and 10.0 < out['loss'] < 12.0  # ln(50280) = 10.83 at init

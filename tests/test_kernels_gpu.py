@@ -206,6 +206,10 @@ def test_swiglu_fwd_bwd(ops, M, h):
 # --------------------------------------------------------------------------------------
 NT_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1000, 2304, 768), (64, 50280, 768), (512, 768, 50280),
              (1, 8, 8), (4096, 768, 2048), (300, 768, 50304), (130, 136, 192)]
+# BASELINE configs[3] (config/tr_420M_x8gpu.yaml:20-24,34: d=1024, h=2816, B=8 x T=2048 -> M=16384) at FULL size: the
+# launch plans bench.py --config 420m runs - w_qkv / w_out / fc1 / fc2 forward and their dX duals
+NT_SHAPES_420M = [(16384, 3072, 1024), (16384, 1024, 1024), (16384, 5632, 1024), (16384, 1024, 2816),
+                  (16384, 1024, 3072), (16384, 1024, 5632), (16384, 2816, 1024)]
 
 
 def test_gemm_families_vs_cpu_matmul(ops):
@@ -242,7 +246,7 @@ def _lib_ws(M, N, K):
   return _lib.load().plm_gemm_nt_workspace_bytes(M, N, K)
 
 
-@pytest.mark.parametrize('M,N,K', NT_SHAPES)
+@pytest.mark.parametrize('M,N,K', NT_SHAPES + NT_SHAPES_420M)
 def test_gemm_nt(ops, M, N, K):
   g = torch.Generator().manual_seed(M + N + K)
   A = bf(torch.randn(M, K, generator=g)).cuda()
@@ -355,7 +359,9 @@ def test_gemm_nt_strided_operand(ops):
 
 
 TN_SHAPES = [(128, 128, 64), (256, 128, 512), (136, 72, 200), (2304, 768, 4096), (768, 2048, 1000), (50280, 768, 256),
-             (8, 8, 8), (768, 768, 32768), (520, 264, 192), (304, 1000, 1024), (4096, 768, 8192), (256, 256, 64), (50280, 768, 2048), (66000, 256, 1024)]
+             (8, 8, 8), (768, 768, 32768), (520, 264, 192), (304, 1000, 1024), (4096, 768, 8192), (256, 256, 64), (50280, 768, 2048), (66000, 256, 1024),
+             # the dW GEMMs of a 420M block at full size (contraction over M = 16384 tokens): w_qkv, w_out, fc1, fc2
+             (3072, 1024, 16384), (1024, 1024, 16384), (5632, 1024, 16384), (1024, 2816, 16384)]
 
 
 @pytest.mark.parametrize('M,N,K', TN_SHAPES)
@@ -383,6 +389,8 @@ def test_gemm_tn(ops, M, N, K):
     ([(768, 2048), (4096, 768), (768, 768), (2304, 768)] * 12, 1024),
     # 6 ragged problems whose 262 tiles straddle the whole-K / split boundary inside one problem
     ([(1000, 1032), (520, 264), (2304, 768), (136, 72), (3000, 1544), (4096, 776)], 1024),
+    # the four dW GEMMs of three 420M blocks (fc2, fc1, w_out, w_qkv; the DDP group size) at the full M = 16384
+    ([(1024, 2816), (5632, 1024), (1024, 1024), (3072, 1024)] * 3, 16384),
 ])
 def test_gemm_tn_grouped(ops, shapes, K):
   """Grouped dW launch (whole-K tiles for the full rounds + split-K remainder) == the individual GEMMs: every problem, overwrite
@@ -408,10 +416,10 @@ def test_gemm_tn_grouped(ops, shapes, K):
     assert torch.equal(o, ops.gemm_tn(a, b))  # small integers: fp32 sums are exact in any order
 
 
-@pytest.mark.parametrize('M,h,K', [(2048, 2048, 768), (1000, 1024, 256), (4096, 128, 128), (300, 72, 200)])
+@pytest.mark.parametrize('M,h,K', [(2048, 2048, 768), (1000, 1024, 256), (4096, 128, 128), (300, 72, 200), (16384, 2816, 1024)])  # last: 420M at full size
 def test_fc1_swiglu_fused_epilogue(ops, M, h, K):
   """fc1 + SwiGLU in one launch (gate / up half-tiles, activation in the GEMM epilogue) == GEMM followed by the stand-alone
-  kernel, bit for bit (u and act); the last two shapes take the unfused fallback of the same entry point."""
+  kernel, bit for bit (u and act); the (4096, 128, 128) and (300, 72, 200) shapes take the unfused fallback of the same entry point."""
   g = torch.Generator(device='cuda').manual_seed(M + h)
   x = bf(torch.randn(M, K, generator=g, device='cuda'))
   w = bf(torch.randn(2 * h, K, generator=g, device='cuda') * 0.05)
@@ -422,10 +430,10 @@ def test_fc1_swiglu_fused_epilogue(ops, M, h, K):
   close(u.float(), x.float() @ w.float().t(), 6e-3, 'fc1_swiglu u vs fp32 matmul')
 
 
-@pytest.mark.parametrize('M,h,K', [(2048, 2048, 768), (1000, 512, 256), (4096, 128, 128), (300, 72, 200)])
+@pytest.mark.parametrize('M,h,K', [(2048, 2048, 768), (1000, 512, 256), (4096, 128, 128), (300, 72, 200), (16384, 2816, 1024)])  # last: 420M at full size
 def test_fc2_dx_swiglu_bwd_fused_epilogue(ops, M, h, K):
-  """dX of fc2 + SwiGLU backward in one launch == GEMM followed by the stand-alone kernel, bit for bit; the last two shapes take
-  the two-launch fallback of the same entry point."""
+  """dX of fc2 + SwiGLU backward in one launch == GEMM followed by the stand-alone kernel, bit for bit; the (4096, 128, 128) and
+  (300, 72, 200) shapes take the two-launch fallback of the same entry point."""
   g = torch.Generator(device='cuda').manual_seed(M + 3 * h)
   dy = bf(torch.randn(M, K, generator=g, device='cuda'))
   w2t = bf(torch.randn(h, K, generator=g, device='cuda') * 0.05)
@@ -530,7 +538,7 @@ def test_rope_qk_golden(ops, golden_dir):
   assert (qkv[:, 2 * d:] == 1).all()  # v untouched
 
 
-@pytest.mark.parametrize('B,T,nh,K', [(4, 256, 2, 128), (8, 1024, 12, 768), (3, 100, 1, 64), (5, 200, 2, 128), (3, 344, 5, 64)])
+@pytest.mark.parametrize('B,T,nh,K', [(4, 256, 2, 128), (8, 1024, 12, 768), (3, 100, 1, 64), (5, 200, 2, 128), (3, 344, 5, 64), (8, 2048, 16, 1024)])  # last: 420M at full size
 def test_qkv_projection_with_rope(ops, B, T, nh, K):
   """Projection GEMM + in-place RoPE pass (plm_qkv_rope_bf16) vs the oracle."""
   g = torch.Generator().manual_seed(B * T + nh)
