@@ -32,6 +32,10 @@ extern "C" {
 
 int plm_version(void);
 const char* plm_last_error_string(void);
+/* The library reads its environment switches (PLM_GEMM_V1, PLM_TN_NO_BIG, PLM_NT_NO_HYBRID, PLM_NT_HYBRID_MIN_K: tests and A/B
+ * runs; none is needed in production) ONCE, at its first call - no launch path calls getenv.  A process that changes one of them
+ * afterwards (the test-suite does) calls this to have them read again. */
+void plm_reload_env(void);
 
 /* ---- parameter casts --------------------------------------------------
  * Replaces autocast's per-forward fp32->bf16 weight casts
@@ -145,7 +149,8 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  * qkv bf16[B*T, 3*nh*hd] straight from w_qkv (q | k | v column blocks, head h = cols h*hd..), hd == 64, T % 4 == 0.
  * rope_cos/sin fp32[T, hd/2] (interleaved-pair convention).  doc_start int32[B,T] or NULL (pure causal):
  * query i attends key j iff doc_start[i] <= j <= i (doc_start non-decreasing in i).
- * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (once per layer; fp32 math, bf16 result).
+ * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (fp32 math, bf16 result).  The training step does not launch it: the
+ *               rotation is fused into plm_qkv_rope_bf16's GEMM epilogue; this is that entry point's fallback and the tests' yardstick.
  * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (BASE-2 log-sum-exp of the
  *               scaled scores, = LSE / ln 2: the form plm_attn_bwd's exp2 consumes; opaque to the caller otherwise).  No transposed / contiguous copies of q, k, v are made anywhere.
  * plm_attn_bwd: same rotated qkv; dqkv bf16[B*T, 3*nh*hd] = gradient w.r.t. the PRE-rotation q, k (the inverse
@@ -153,8 +158,11 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  *               kernel and read by the dK/dV kernel that follows it). */
 int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                 void* stream);
-/* w_qkv projection + RoPE (transformer.py:42-47): QKV[M, 3*nh*hd] = X[M,K] W[3*nh*hd, K]^T, then the q | k blocks are
- * rotated in place by plm_rope_qk (one HBM pass; ldq must be 3*nh*hd). */
+/* w_qkv projection + RoPE (transformer.py:42-47): QKV[M, 3*nh*hd] = X[M,K] W[3*nh*hd, K]^T with the q | k column blocks rotated
+ * (ldq must be 3*nh*hd).  Default path: ONE launch - the rotation happens on the store side of the GEMM's epilogue (the bf16 values
+ * the GEMM would have written are rotated on their way from the epilogue's LDS transposition scratch to memory; K % 64 == 0,
+ * M >= 512, 16-byte aligned operands).  Other shapes, and PLM_GEMM_V1, take the fallback: the plain GEMM followed by the in-place
+ * plm_rope_qk pass.  Both paths produce the same bits. */
 int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, uint16_t* QKV, int64_t ldq, int64_t M,
                       int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                       void* stream);

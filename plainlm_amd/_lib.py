@@ -17,7 +17,7 @@ _lib = None
 
 # ABI the signatures below were written for (plm_version() of the library must match: a stale .so that still exports every
 # symbol but with other argument lists / struct layouts would corrupt memory instead of raising)
-EXPECTED_ABI = 103
+EXPECTED_ABI = 104
 
 _P = C.c_void_p
 _I64 = C.c_int64
@@ -45,6 +45,7 @@ class TnProblem(C.Structure):
 SIGNATURES = {
   'plm_version': (_I, []),
   'plm_last_error_string': (C.c_char_p, []),
+  'plm_reload_env': (None, []),
   'plm_cast_f32_bf16': (_I, [_P, _P, _I64, _P]),
   'plm_cast_f32_bf16_t': (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
   'plm_cast_f32_bf16_t_multi': (_I, [C.POINTER(CastItem), _I, _P]),

@@ -555,6 +555,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 // =============================================================================================
 // C ABI
 // =============================================================================================
+// second-generation kernels (attn_v2.hip); variant 0 = the first-generation kernels of this file
+void plm_attn_fwd2(int variant, const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s);
+void plm_attn_dq2(int variant, const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
+                  const float* rs, const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);
+void plm_attn_dkdv2(int variant, const uint16_t* qkv, const uint16_t* dout, const float* lse, const float* delta, const float* rc,
+                    const float* rs, const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);
+static int attn_variant(int env_value, int dflt) { return env_value >= 0 ? env_value : dflt; }
+
 static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, int64_t hd) {
   PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
   PLM_REQUIRE(B > 0 && T > 0 && nh > 0 && B < 65536 && nh < 65536 && T < (1 << 24), "%s: bad shape B=%ld T=%ld nh=%ld", name, (long)B,
@@ -581,6 +589,11 @@ extern "C" int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint1
   if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
   const dim3 grid((unsigned)(plm_cdiv(T, 128) * nh * B)), block(256);  // see attn_block
   hipStream_t s = (hipStream_t)stream;
+  if (const int v = attn_variant(plm_env().attn_fwd, 22)) {
+    plm_attn_fwd2(v, qkv, doc_start, out, lse, B, T, nh, s);
+    PLM_CHECK_LAUNCH("plm_attn_fwd");
+    return PLM_OK;
+  }
   if (doc_start)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
   else
@@ -598,13 +611,19 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   const dim3 block(256);
   // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
   const dim3 gkv((unsigned)(plm_cdiv(T, 128) * nh * B));
-  if (doc_start) {
+  const int vq = attn_variant(plm_env().attn_dq, 22), vk = attn_variant(plm_env().attn_dkdv, 21);
+  if (vq)
+    plm_attn_dq2(vq, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, B, T, nh, s);
+  else if (doc_start)
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-  } else {
+  else
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+  if (vk)
+    plm_attn_dkdv2(vk, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, B, T, nh, s);
+  else if (doc_start)
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+  else
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-  }
   PLM_CHECK_LAUNCH("plm_attn_bwd");
   return PLM_OK;
 }

@@ -322,7 +322,7 @@ extern "C" int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_
   const int tiles_m = (int)plm_cdiv(M, GBM), tiles_n = (int)plm_cdiv(N, GBN);
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  static const bool force_v1 = getenv("PLM_GEMM_V1") != nullptr;
+  const bool force_v1 = plm_env().gemm_v1;
   const bool dma_shape = (K % GBK == 0) && (N % 8 == 0) && (ldc % 8 == 0);
   PLM_REQUIRE(variant <= 1 || dma_shape, "plm_gemm_bf16_nt_ex: variant %d needs K %% 64 == 0, N %% 8 == 0, ldc %% 8 == 0", variant);
   PLM_REQUIRE(variant <= 2 || c_dtype == 0, "plm_gemm_bf16_nt_ex: the big-tile variants write bf16 C only");
@@ -373,7 +373,7 @@ extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t*
   PLM_REQUIRE(hd == 64 && B > 0 && T > 0 && nh > 0 && M == B * T, "plm_qkv_rope_bf16: bad shape (hd must be 64, M == B*T)");
   const int64_t N = 3 * nh * hd;
   PLM_REQUIRE(ldq == N, "plm_qkv_rope_bf16: needs a dense output (ldq == 3*nh*hd)");
-  if (getenv("PLM_GEMM_V1") == nullptr &&
+  if (!plm_env().gemm_v1 &&
       plm_launch_gemm_nt_rope(X, ldx, W, ldw, QKV, ldq, M, N, K, rope_cos, rope_sin, T, 2 * nh * hd, (hipStream_t)stream)) {
     PLM_CHECK_LAUNCH("plm_qkv_rope_bf16");
     return PLM_OK;
@@ -393,7 +393,7 @@ extern "C" int plm_fc1_swiglu_bf16(const uint16_t* X, int64_t ldx, const uint16_
   PLM_REQUIRE(X && W && U && ACT, "plm_fc1_swiglu_bf16: null pointer");
   PLM_REQUIRE(M > 0 && h > 0 && K > 0 && h % 8 == 0, "plm_fc1_swiglu_bf16: bad shape (h %% 8 == 0)");
   const int64_t N = 2 * h;
-  if (getenv("PLM_GEMM_V1") == nullptr && plm_launch_gemm_nt_glu(X, ldx, W, ldw, U, N, ACT, h, M, N, K, (hipStream_t)stream)) {
+  if (!plm_env().gemm_v1 && plm_launch_gemm_nt_glu(X, ldx, W, ldw, U, N, ACT, h, M, N, K, (hipStream_t)stream)) {
     PLM_CHECK_LAUNCH("plm_fc1_swiglu_bf16");
     return PLM_OK;
   }
@@ -411,7 +411,7 @@ extern "C" int plm_fc2_dx_swiglu_bwd_bf16(const uint16_t* dY, int64_t lddy, cons
                                           uint16_t* scratch, int64_t M, int64_t h, int64_t K, void* stream) {
   PLM_REQUIRE(dY && W2T && U && DU, "plm_fc2_dx_swiglu_bwd_bf16: null pointer");
   PLM_REQUIRE(M > 0 && h > 0 && K > 0 && h % 8 == 0, "plm_fc2_dx_swiglu_bwd_bf16: bad shape (h %% 8 == 0)");
-  if (getenv("PLM_GEMM_V1") == nullptr && plm_launch_gemm_nt_glub(dY, lddy, W2T, ldw, U, 2 * h, DU, 2 * h, M, h, K, (hipStream_t)stream)) {
+  if (!plm_env().gemm_v1 && plm_launch_gemm_nt_glub(dY, lddy, W2T, ldw, U, 2 * h, DU, 2 * h, M, h, K, (hipStream_t)stream)) {
     PLM_CHECK_LAUNCH("plm_fc2_dx_swiglu_bwd_bf16");
     return PLM_OK;
   }
@@ -689,7 +689,7 @@ void plm_launch_gemm_tn_big(int splits, int rfull, int accumulate, const uint16_
 static int tn_plan(int64_t M, int64_t N, int64_t K, bool& big, int& rfull) {
   big = false;
   rfull = 0;
-  if (getenv("PLM_TN_NO_BIG") == nullptr && getenv("PLM_GEMM_V1") == nullptr) {
+  if (!plm_env().tn_no_big && !plm_env().gemm_v1) {
     int sb = 1;
     if (plm_tn_big_plan(M, N, K, &sb, &rfull)) {
       big = true;
@@ -749,7 +749,7 @@ extern "C" int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* 
     PLM_CHECK_LAUNCH("plm_gemm_bf16_tn (big tile)");
     return PLM_OK;
   }
-  static const bool force_v1 = getenv("PLM_GEMM_V1") != nullptr;
+  const bool force_v1 = plm_env().gemm_v1;
   const bool dma_ok = !force_v1 && (K % GBK == 0);
   if (splits == 1) {
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1);

@@ -1150,12 +1150,12 @@ bool plm_nt_hybrid_plan(int64_t M, int64_t N, int64_t K, NtHybridPlan* p) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (getenv("PLM_NT_NO_HYBRID") != nullptr) return false;
-  const char* mk = getenv("PLM_NT_HYBRID_MIN_K");  // tests / A-B runs lower the thresholds
+  if (plm_env().nt_no_hybrid) return false;
+  const bool mk = plm_env().nt_hybrid_min_k >= 0;  // tests / A-B runs lower the thresholds
   // measured (profiles/r01_kbench_run18*): the fp32 slab traffic (~40 us) only pays off for long K - on the whole chip.  With CUs set
   // aside for RCCL (240 slots) every plain tiling of the N = 768 shapes loses 20 % to round quantisation and the hybrid pays from
   // K = 2048 (run 38: +0.4 % end to end under a 16-CU reserve)
-  const int64_t min_k = mk ? atoll(mk) : (g_cu_reserve > 0 ? 2048 : 8192), min_l = mk ? 2 : 8;
+  const int64_t min_k = mk ? plm_env().nt_hybrid_min_k : (g_cu_reserve > 0 ? 2048 : 8192), min_l = mk ? 2 : 8;
   if (K % 64 != 0 || N % 8 != 0 || M < 2048 || N < 256 || K < min_k) return false;
   const int slots = persistent_slots();
   const int64_t R = plm_cdiv(M, 256), Cn = plm_cdiv(N, 256), tiles = R * Cn, nkt = K / 64;

@@ -1,5 +1,6 @@
 // Error plumbing, version, and the hardware-semantics probes used by the GPU tests.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "plm_device.h"
@@ -14,7 +15,31 @@ void plm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* plm_last_error_string(void) { return g_err; }
-extern "C" int plm_version(void) { return 103; }  // 102: round 2 (see include/plainlm_hip.h); 101: + plm_gemm_bf16_nt_ws, plm_gemm_nt_workspace_bytes, plm_embed_bwd_sorted, plm_embed_bwd_workspace_bytes; base-2 LSE
+extern "C" int plm_version(void) { return 104; }  // 104: round 3 (+ plm_reload_env); 103 / 102: round 2 (see include/plainlm_hip.h); 101: round 1
+
+static PlmEnv g_env;
+static void load_env() {
+  auto num = [](const char* name) -> long long {
+    const char* e = getenv(name);
+    return e ? atoll(e) : -1;
+  };
+  g_env.gemm_v1 = getenv("PLM_GEMM_V1") != nullptr;
+  g_env.tn_no_big = getenv("PLM_TN_NO_BIG") != nullptr;
+  g_env.nt_no_hybrid = getenv("PLM_NT_NO_HYBRID") != nullptr;
+  g_env.nt_hybrid_min_k = num("PLM_NT_HYBRID_MIN_K");
+  g_env.attn_fwd = (int)num("PLM_ATTN_FWD");
+  g_env.attn_dq = (int)num("PLM_ATTN_DQ");
+  g_env.attn_dkdv = (int)num("PLM_ATTN_DKDV");
+}
+const PlmEnv& plm_env() {
+  static const bool once = (load_env(), true);
+  (void)once;
+  return g_env;
+}
+extern "C" void plm_reload_env(void) {
+  (void)plm_env();
+  load_env();
+}
 
 // ---------------------------------------------------------------------------
 // probe: what does ds_read_b64_tr_b16 deliver?  LDS holds 0,1,2,...; lane l reads at byte 8*l.

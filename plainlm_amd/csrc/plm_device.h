@@ -31,6 +31,17 @@ void plm_set_error(const char* fmt, ...);
 
 static inline int64_t plm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Environment switches of the library (tests / A-B runs), read ONCE at the first call and again only on plm_reload_env():
+// no getenv on any launch path.
+struct PlmEnv {
+  bool gemm_v1;               // PLM_GEMM_V1: register-staged 128x128 GEMMs everywhere (the fused entry points take their two-launch paths)
+  bool tn_no_big;             // PLM_TN_NO_BIG: no persistent 256x256 TN kernel
+  bool nt_no_hybrid;          // PLM_NT_NO_HYBRID: no whole-K + stream-K NT schedule
+  long long nt_hybrid_min_k;  // PLM_NT_HYBRID_MIN_K: lowers the hybrid schedule's thresholds (-1: defaults)
+  int attn_fwd, attn_dq, attn_dkdv;  // PLM_ATTN_FWD / _DQ / _DKDV: attention kernel variants (A/B runs; -1: defaults)
+};
+const PlmEnv& plm_env();
+
 // ---------------------------------------------------------------------------
 // device-side types
 // ---------------------------------------------------------------------------

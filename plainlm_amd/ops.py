@@ -234,10 +234,21 @@ def cu_reserve():
   return _cu_reserve
 
 
+_env_epoch = 0
+
+
+def reload_env():
+  """Have the library read its PLM_* environment switches again (it reads them once, at its first call; tests and A/B tools
+  that change os.environ afterwards call this)."""
+  global _env_epoch
+  _lib.load().plm_reload_env()
+  _env_epoch += 1
+
+
 def _nt_ws_bytes(lib, M, N, K):
-  """Workspace query of the hybrid NT schedule, cached per shape (the plan depends on the shape, the PLM_NT_* environment knobs
-  and the CU reserve - all part of the key)."""
-  key = (M, N, K, _cu_reserve, os.environ.get('PLM_NT_NO_HYBRID'), os.environ.get('PLM_NT_HYBRID_MIN_K'))
+  """Workspace query of the hybrid NT schedule, cached per shape (the plan depends on the shape, the library's environment
+  switches - see reload_env - and the CU reserve: all part of the key)."""
+  key = (M, N, K, _cu_reserve, _env_epoch)
   v = _nt_ws_cache.get(key)
   if v is None:
     v = _nt_ws_cache[key] = int(lib.plm_gemm_nt_workspace_bytes(M, N, K))
@@ -385,7 +396,7 @@ def fc2_dx_swiglu_bwd(dy, w2t, u):
 
 # ---- attention ----------------------------------------------------------------------
 def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
-  """Rotate the q and k column blocks of the projection output in place (once per layer)."""
+  """Rotate the q and k column blocks of a projection output in place (qkv_rope's fallback; the step uses the fused epilogue)."""
   _need(qkv, BF16, 'rope_qk.qkv', 2)
   hd = qkv.shape[1] // (3 * nh)
   _need(rope_cos, F32, 'rope_qk.rope_cos', 2)
@@ -397,7 +408,8 @@ def rope_qk_(qkv, rope_cos, rope_sin, B, T, nh):
 
 
 def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
-  """qkv[M, 3d] = x @ w_qkv^T with q | k rotated (projection GEMM + the one-pass in-place RoPE kernel)."""
+  """qkv[M, 3d] = x @ w_qkv^T with q | k rotated: one launch, the rotation in the GEMM's store-side epilogue (shapes that do
+  not qualify: GEMM + the in-place rope_qk_ pass, same bits)."""
   _need(x, BF16, 'qkv_rope.x', 2)
   _need(w_qkv, BF16, 'qkv_rope.w', 2)
   M, K = x.shape

@@ -25,6 +25,18 @@ def ops():
   return _ops
 
 
+@pytest.fixture
+def plm_env(monkeypatch, ops):
+  """Set one of the library's environment switches for one test: the library caches them (no getenv on a launch path), so it is
+  told to read them again now and once more when the test's environment has been restored."""
+  def set_(name, value):
+    monkeypatch.setenv(name, value)
+    ops.reload_env()
+  yield set_
+  monkeypatch.undo()
+  ops.reload_env()
+
+
 def relerr(a, ref):
   a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
   return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
@@ -284,12 +296,12 @@ def test_gemm_nt_variants(ops, M, N, K, variant):
 
 @pytest.mark.parametrize('M,N,K', [(32768, 768, 768), (32768, 768, 2048), (32700, 1032, 1024), (32768, 768, 50304), (20480, 1280, 640),
                                    (32768, 768, 576), (32768, 768, 4096)])
-def test_gemm_nt_hybrid(ops, M, N, K, monkeypatch):
+def test_gemm_nt_hybrid(ops, M, N, K, plm_env):
   """Shapes whose 256x256 tile count is a bad multiple of the CU count take the hybrid whole-K + stream-K schedule
   (workspace > 0 asserts that): ragged M/N tails inside the stream-K rows, runs that cross tile boundaries, alpha,
   padded ldc; plus bit-equality with the plain schedule on exactly-representable inputs."""
   from plainlm_amd import _lib
-  monkeypatch.setenv('PLM_NT_HYBRID_MIN_K', '64')
+  plm_env('PLM_NT_HYBRID_MIN_K', '64')
   assert _lib.load().plm_gemm_nt_workspace_bytes(M, N, K) > 0, 'shape does not exercise the hybrid schedule'
   g = torch.Generator(device='cuda').manual_seed(M + N + K)
   A = bf(torch.randn(M, K, generator=g, device='cuda'))
@@ -308,10 +320,10 @@ def test_gemm_nt_hybrid(ops, M, N, K, monkeypatch):
   assert torch.equal(hyb, plain)  # integer inputs: fp32 sums are exact in any order
 
 
-def test_gemms_with_cu_reserve(ops, monkeypatch):
+def test_gemms_with_cu_reserve(ops, plm_env):
   """Multi-GPU runs reserve 16 CUs for RCCL while gradient buckets are in flight (ddp.GradReducer -> ops.set_cu_reserve): the persistent grids shrink to 240
   workgroups and every plan (tile choice, hybrid stream-K, TN split) is recomputed for that count.  Same answers required."""
-  monkeypatch.setenv('PLM_NT_HYBRID_MIN_K', '64')
+  plm_env('PLM_NT_HYBRID_MIN_K', '64')
   g = torch.Generator(device='cuda').manual_seed(11)
   M, d, h = 16384, 768, 2048
   fx = bf(torch.randn(M, d, generator=g, device='cuda'))
@@ -442,10 +454,10 @@ def test_fc2_dx_swiglu_bwd_fused_epilogue(ops, M, h, K):
   assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(dy, w2t), u))
 
 
-def test_fused_entry_points_fall_back_under_gemm_v1(ops, monkeypatch):
+def test_fused_entry_points_fall_back_under_gemm_v1(ops, plm_env):
   """PLM_GEMM_V1=1 forces the register-staged 128x128 GEMMs: the three entry points with fused epilogues must then take their
   two-launch paths (the backward one asks for its d(act) scratch with PLM_E_WORKSPACE and gets it) and still be right."""
-  monkeypatch.setenv('PLM_GEMM_V1', '1')
+  plm_env('PLM_GEMM_V1', '1')
   g = torch.Generator(device='cuda').manual_seed(5)
   M, d, h = 1024, 256, 512
   x = bf(torch.randn(M, d, generator=g, device='cuda'))

@@ -29,6 +29,7 @@ def main():
       os.environ.pop('PLM_NT_HYBRID_MIN_K', None)
     else:
       os.environ['PLM_NT_HYBRID_MIN_K'] = '64'
+    ops.reload_env()
     if kind == 'nt':
       M = rnd.choice([8, 136, 256, 1000, 4096, 8192, 20480, 32768, 33000]) + 8 * rnd.randint(0, 3)
       N = rnd.choice([8, 72, 256, 392, 768, 1032, 2304, 4096]) + 8 * rnd.randint(0, 2)

@@ -89,8 +89,10 @@ def main():
       rec(name, timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
       if _lib.load().plm_gemm_nt_workspace_bytes(m, n, k) > 0:
         os.environ['PLM_NT_NO_HYBRID'] = '1'
+        ops.reload_env()
         rec(name + ' [no hybrid]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
         del os.environ['PLM_NT_NO_HYBRID']
+        ops.reload_env()
       if k % 64 == 0 and a.variants:
         for v, vn in ((2, 'dma128'), (3, 'plain256x256'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
@@ -125,8 +127,10 @@ def main():
       rec(name, timeit(lambda: ops.gemm_tn(A, Bm, out=out, accumulate=True), a.iters), flops=2.0 * m * n * k)
       if a.variants:
         os.environ['PLM_TN_NO_BIG'] = '1'
+        ops.reload_env()
         rec(name + ' [dma128]', timeit(lambda: ops.gemm_tn(A, Bm, out=out, accumulate=True), a.iters), flops=2.0 * m * n * k)
         del os.environ['PLM_TN_NO_BIG']
+        ops.reload_env()
       del A, Bm, out
 
   if want('gemm'):
