@@ -251,6 +251,255 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd2_kernel(const uint16_t* __
 }
 
 // =============================================================================================
+// forward, third form: one workgroup = 4 waves x 64 query rows (256-row tiles), wave w owns the 32-row blocks w and 7 - w of the tile -
+// every wave of a causal tile then has the same amount of work (block w ends 7 - 2w blocks before block 7 - w) and no wave idles through
+// the diagonal region; K / V tiles of 64 rows go through an NST-deep LDS ring filled NST - 1 tiles ahead (counted vmcnt waits: the wait
+// in front of tile i only covers tile i), one barrier per tile.
+// Per tile a row block is OFF (tile above its diagonal), UM (no mask needed) or MASK.
+// =============================================================================================
+enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };
+
+template <bool HAS_DOC, int NST, int MINW, int ABL = 0>
+__global__ __launch_bounds__(256, MINW) void attn_fwd3_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
+                                                              uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
+  constexpr int KT = 64;
+  constexpr int TILE = KT * 128;  // 8 KiB
+  constexpr int QB = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];  // [stage][K|V]
+
+  int tile_, h, b;
+  attn_block2<QB>(T, nh, tile_, h, b);
+  const int qt = (T + QB - 1) / QB - 1 - tile_;
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int q0 = qt * QB;
+  const int r0[2] = {q0 + 32 * wave, q0 + 32 * (7 - wave)};  // first rows of this wave's two blocks
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const float c2 = 0.125f * LOG2E;  // 1/sqrt(64) and the base-2 exponent in one factor
+
+  bf16x8_t qf[2][4];
+  int dsq[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    const bool qvalid = qrow < T;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
+    dsq[qb] = 0;
+    if (HAS_DOC && qvalid) dsq[qb] = doc_start[(int64_t)b * T + qrow];
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+    asm volatile("; q fragments resident" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]), "v"(dsq[qb]));  // consumed before any DMA is in flight
+
+  f32x16_t o[2][2];
+  float mc[2], lsum[2];  // running reference maximum in log2 units (s * c2), running sum
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    zero16(o[qb][0]);
+    zero16(o[qb][1]);
+    mc[qb] = -INFINITY;
+    lsum[qb] = 0.f;
+  }
+
+  const int kv_hi = min(T, q0 + QB);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  int jt_lo = 0;
+  if (HAS_DOC) jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
+  const int n = jt_hi - jt_lo;
+
+  TileDma dma;
+  dma.init(wave, lane, ld);
+  auto stage = [&](int slot, int jt) {  // 4 LDS-DMA instructions per wave
+    if (ABL & 16) return;
+    const int kv0 = jt * KT;
+    const uint16_t* src = base + (int64_t)kv0 * ld;
+    if (kv0 + KT <= T) {  // whole tile inside the sequence (always, when T % 64 == 0): no per-lane address arithmetic
+      dma.issue_full(smem + slot * 2 * TILE, src + dm, wave);
+      dma.issue_full(smem + slot * 2 * TILE + TILE, src + 2 * dm, wave);
+    } else {
+      dma.issue(smem + slot * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+      dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    }
+  };
+
+  // one row block's softmax + P V for one tile (s: its S^T accumulators, vfr: the tile's V fragments)
+  auto soft_pv = [&](int qb_, f32x16_t (&s)[2], const bf16x8_t (&vfr)[2][4], int kv0, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const int qb = qb_;
+    if (ABL & 64) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          f32x4_t t4 = {s[sp >> 1][(sp & 1) * 8], s[sp >> 1][(sp & 1) * 8 + 1], s[sp >> 1][(sp & 1) * 8 + 2], s[sp >> 1][(sp & 1) * 8 + 3]};
+          const bf16x8_t pq = __builtin_bit_cast(bf16x8_t, t4);
+          if (ABL & 4)
+            asm volatile("" : "+v"(o[qb][db]) : "v"(vfr[db][sp]), "v"(pq));
+          else
+            o[qb][db] = mfma32(vfr[db][sp], pq, o[qb][db]);
+        }
+      return;
+    }
+    // key (kb, r) of this lane is tile row kb*32 + (r&3) + 8*(r>>2) + 4*hi: visible iff  c_lo <= kb*32 + (r&3) + 8*(r>>2) <= c_hi
+    const int c_hi = r0[qb] + l31 - kv0 - 4 * hi;
+    const int c_lo = HAS_DOC ? dsq[qb] - kv0 - 4 * hi : 0;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+          const bool ok = (c <= c_hi) && (!HAS_DOC || c >= c_lo);
+          if (!ok) s[kb][r] = -INFINITY;
+        }
+        tmax = fmaxf(tmax, s[kb][r]);
+      }
+    {
+      float t_lo, t_hi;
+      half_pair(tmax, t_lo, t_hi);
+      tmax = fmaxf(t_lo, t_hi);
+    }
+    const float tm = tmax * c2;
+    const bool need = tm > mc[qb] + ATTN_DEFER_LOG2;  // both -inf (nothing visible yet): false
+    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {   // wave-uniform and rare after the first tile
+      const float mn = fmaxf(mc[qb], tm);
+      const float alpha = fast_exp2(mc[qb] - ((mn == -INFINITY) ? 0.f : mn));
+      mc[qb] = mn;
+      lsum[qb] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+    }
+    const float mref = (MASK && mc[qb] == -INFINITY) ? 0.f : mc[qb];
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float px = __builtin_fmaf(s[kb][r], c2, -mref);
+        const float p = (ABL & 1) ? px : fast_exp2(px);
+        ps[r & 3] += p;
+        pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
+      }
+    lsum[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        if (ABL & 4)
+          asm volatile("" : "+v"(o[qb][db]) : "v"(vfr[db][sp]), "v"(pf[sp]));
+        else
+          o[qb][db] = mfma32(vfr[db][sp], pf[sp], o[qb][db]);
+      }
+  };
+
+  // one KV tile: S^T = K Q^T for the active row blocks, then softmax + P V per block.  M0 / M1: mode of block 0 / 1.
+  auto compute = [&](int kv0, const char* sK, const char* sV, auto m0_tag, auto m1_tag) {
+    constexpr int M0 = decltype(m0_tag)::value, M1 = decltype(m1_tag)::value;
+    bf16x8_t kfr[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kfr[kb][ks] = (ABL & 8) ? qf[0][ks] : frag_rows(sK, kb * 32 + l31, ks, hi);
+        if (ABL & 8) asm volatile("" : "+v"(kfr[kb][ks]));
+      }
+    f32x16_t s[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if ((qb == 0 ? M0 : M1) == QB_OFF) continue;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        zero16(s[qb][kb]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ABL & 2)
+            asm volatile("" : "+v"(s[qb][kb]) : "v"(kfr[kb][ks]));
+          else
+            s[qb][kb] = mfma32(kfr[kb][ks], qf[qb][ks], s[qb][kb]);
+        }
+      }
+    }
+    if (MINW > 1) __builtin_amdgcn_sched_barrier(0);  // 256 registers: keep the V fragments out of the Q K^T phase
+    bf16x8_t vfr[2][4];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        vfr[db][sp] = (ABL & 8) ? qf[0][sp] : frag_cols(sV, db, (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi, lane);
+        if (ABL & 8) asm volatile("" : "+v"(vfr[db][sp]));
+      }
+    if (M0 == QB_UM) soft_pv(0, s[0], vfr, kv0, std::false_type{});
+    if (M0 == QB_MASK) soft_pv(0, s[0], vfr, kv0, std::true_type{});
+    if (M1 == QB_UM) soft_pv(1, s[1], vfr, kv0, std::false_type{});
+    if (M1 == QB_MASK) soft_pv(1, s[1], vfr, kv0, std::true_type{});
+  };
+
+  // ring: tile i = jt - jt_lo lives in slot i % NST; tiles are issued NST - 1 ahead
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < n) stage(i, jt_lo + i);
+  int i = 0, slot = 0;
+  auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
+    for (; jt_lo + i < jt_end; ++i) {
+      // wait for this wave's pieces of tile i: the tiles issued after it (at most NST - 2, fewer at the end) may stay in flight
+      const int rem = min(NST - 2, n - 1 - i);
+      if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
+      else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+      else attn_wait_vm<0>();
+      if (!(ABL & 32)) attn_barrier();  // everyone's pieces landed; and every wave is done reading tile i - 1, whose slot is refilled now
+      if (i + NST - 1 < n) stage(slot == 0 ? NST - 1 : slot - 1, jt_lo + i + NST - 1);
+      if (active) compute((jt_lo + i) * KT, smem + slot * 2 * TILE, smem + slot * 2 * TILE + TILE, m0_tag, m1_tag);
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+    }
+  };
+  using OFF_ = std::integral_constant<int, QB_OFF>;
+  using UM_ = std::integral_constant<int, QB_UM>;
+  using MK_ = std::integral_constant<int, QB_MASK>;
+  // block qb: tiles [0, r0/64) need no mask, tile r0/64 holds its diagonal, later tiles are above it; rows beyond T compute on zeros
+  const int a0 = min(jt_hi, r0[0] / KT), e0 = min(jt_hi, r0[0] / KT + 1);
+  const int a1 = min(jt_hi, r0[1] / KT), e1 = min(jt_hi, r0[1] / KT + 1);
+  if (HAS_DOC) {
+    run(e0, MK_{}, MK_{}, true);
+    run(e1, OFF_{}, MK_{}, true);
+  } else {
+    run(a0, UM_{}, UM_{}, true);
+    run(e0, MK_{}, UM_{}, true);
+    run(a1, OFF_{}, UM_{}, true);
+    run(e1, OFF_{}, MK_{}, true);
+  }
+  run(jt_hi, OFF_{}, OFF_{}, false);
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    float l_lo, l_hi;
+    half_pair(lsum[qb], l_lo, l_hi);
+    const float ltot = l_lo + l_hi;
+    if (qrow < T) {
+      const float inv = 1.f / ltot;
+      uint16_t* op = out + ((int64_t)b * T + qrow) * dm + h * HD;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4_t v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[qb][db][4 * g + e] * inv);
+          st_bf16x4(op + db * 32 + 8 * g + 4 * hi, v);
+        }
+      if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = mc[qb] + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
+    }
+  }
+}
+
+// =============================================================================================
 // backward: dQ  (one workgroup = 4 waves x (32 * NQB) query rows; key tiles of 64 rows; q, k rotated)
 // Also computes delta[q] = sum_d dO[q][d] O[q][d] for its rows and publishes it for the dK/dV kernel, which runs after it.
 // =============================================================================================
@@ -657,6 +906,14 @@ static void launch_fwd2(const uint16_t* qkv, const int32_t* doc_start, uint16_t*
   else
     hipLaunchKernelGGL((attn_fwd2_kernel<false, NB, MINW, ABL>), grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
 }
+template <int NST, int MINW, int ABL = 0>
+static void launch_fwd3(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
+  const dim3 grid((unsigned)(plm_cdiv(T, 256) * nh * B)), block(256);
+  if (doc_start && ABL == 0)
+    hipLaunchKernelGGL((attn_fwd3_kernel<true, NST, MINW, 0>), grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
+  else
+    hipLaunchKernelGGL((attn_fwd3_kernel<false, NST, MINW, ABL>), grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
+}
 template <int NB, int MINW>
 static void launch_dq2(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
                        const float* rs, const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
@@ -683,6 +940,13 @@ void plm_attn_fwd2(int variant, const uint16_t* qkv, const int32_t* doc_start, u
   switch (variant) {
     case 21: launch_fwd2<2, 1>(qkv, doc_start, out, lse, B, T, nh, s); break;
     case 12: launch_fwd2<1, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 32: launch_fwd3<2, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 33: launch_fwd3<3, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 34: launch_fwd3<4, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 3234: launch_fwd3<4, 2, 32>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 1634: launch_fwd3<4, 2, 16>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 6434: launch_fwd3<4, 2, 64>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 12634: launch_fwd3<4, 2, 126>(qkv, doc_start, out, lse, B, T, nh, s); break;
 #define ABLV(a)                                                                         \
   case 22 + 100 * a: launch_fwd2<2, 2, a>(qkv, doc_start, out, lse, B, T, nh, s); break; \
   case 12 + 100 * a: launch_fwd2<1, 2, a>(qkv, doc_start, out, lse, B, T, nh, s); break;
