@@ -59,10 +59,10 @@ struct TileDma {
       boff[i] = (unsigned)((row[i] * ld + coff[i]) * 2);
     }
   }
-  __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave) const {
+  __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave, int row0 = 0) const {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      dma16_asm(src + (int64_t)min(row[i], last_row) * ld + coff[i], dst_tile + (i * 4 + wave) * 1024);
+    for (int i = 0; i < 2; ++i)  // tile row r is source row row0 + r, clamped to last_row
+      dma16_asm(src + (int64_t)min(row0 + row[i], last_row) * ld + coff[i], dst_tile + (i * 4 + wave) * 1024);
   }
   // full tile (no row clamp), row stride = the one given to init(): wave-uniform base in SGPRs + constant lane offsets
   __device__ __forceinline__ void issue_full(char* dst_tile, const uint16_t* src, int wave) const {

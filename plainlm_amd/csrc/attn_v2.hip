@@ -500,6 +500,351 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd3_kernel(const uint16_t* __
 }
 
 // =============================================================================================
+// forward, persistent form.  At T = 1024 / head_dim 64 the forward pass moves 200 MB through HBM (q, k, v in, o out: ~37 us at the
+// achievable rate) for 23 us of MFMA work at peak: a workgroup that loads its Q rows, computes, then stores O leaves the memory system
+// idle while it computes and the matrix pipe idle while it loads and stores (measured on the non-persistent kernel above: 31 us of
+// the 87 are the Q loads + O stores of the workgroups, 15 us the K / V DMA).  Here 2 workgroups per CU stay resident and walk a list of
+// (256-query tile, head, batch) items, heaviest first; EVERYTHING an item reads arrives through one LDS ring that never drains:
+//   step 0, 1 of an item: its Q rows (2 x 128 rows = 2 x 16 KiB), steps 2..: its K | V tiles of 64 keys (16 KiB each),
+// issued NST - 1 steps ahead of their consumption, across item boundaries - the next item's Q and first K / V tiles are in flight while
+// the current item finishes.  O leaves through a per-wave LDS transposition as whole 128-byte rows (16-byte stores, 8 lanes per row)
+// and nobody waits for those stores.  Wave w owns the 32-row blocks w and 7 - w of the tile (equal causal work for every wave).
+// =============================================================================================
+struct Fwd4Item {
+  int q0, b, h, jt_lo, jt_hi;
+  bool valid;
+};
+
+template <bool HAS_DOC, int NST, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void attn_fwd4_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
+                                                           uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh, int nbh, int n_items,
+                                                           unsigned* __restrict__ sched) {
+  constexpr int KT = 64;
+  constexpr int TILE = KT * 128;  // 8 KiB
+  constexpr int QB = 256;
+  constexpr int OST = 4096;       // per-wave O staging: 32 rows x 128 bytes
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE + 4 * OST + (HAS_DOC ? 2048 : 0)];
+  __shared__ int ids[4];  // ids[k & 3]: list index of this workgroup's k-th item (k >= 1), fetched two items ahead by wave 0
+  char* const ostage = smem + NST * 2 * TILE;
+  int* const dstage = reinterpret_cast<int*>(smem + NST * 2 * TILE + 4 * OST);  // [2][256] doc starts of the current / next item's rows
+
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int ntile = (T + QB - 1) / QB;
+  const int G = gridDim.x, g = blockIdx.x;
+  const float c2 = 0.125f * LOG2E;  // 1/sqrt(64) and the base-2 exponent in one factor
+
+  // The item list is sorted heaviest (latest query tile) first.  Workgroup g starts with item g; every further item is the next one
+  // nobody has taken (one device-wide counter, bumped by wave 0 two items ahead of the consumer and handed to the other waves through
+  // LDS): whichever workgroup is free takes the next-heaviest item, so all of them end within one light item of each other.  (A static
+  // deal of the 1536 items of the 160M shape left the average SIMD 1.46 of 2 waves busy.)
+  auto fetch_id = [&](int k) {  // wave 0 only; the compiler's vmcnt(0) in front of the LDS write drains this wave's DMA once per item
+    const int v = (lane == 0) ? (int)atomicAdd(sched, 1u) : 0;
+    if (lane == 0) ids[k & 3] = min(G + v, n_items);
+  };
+  auto load_item = [&](int k) {
+    Fwd4Item it;
+    const int idx = (k == 0) ? g : __builtin_amdgcn_readfirstlane(ids[k & 3]);
+    it.valid = idx < n_items;
+    const int rank = it.valid ? idx / nbh : 0, bh = it.valid ? idx % nbh : 0;
+    it.q0 = (ntile - 1 - rank) * QB;
+    it.h = bh % nh;
+    it.b = bh / nh;
+    it.jt_hi = (min(T, it.q0 + QB) + KT - 1) / KT;
+    it.jt_lo = 0;
+    if (HAS_DOC && it.valid) it.jt_lo = doc_start[(int64_t)it.b * T + it.q0] / KT;  // wave-uniform address: a scalar load
+    return it;
+  };
+
+  if (wave == 0) fetch_id(1);
+  __syncthreads();
+  TileDma dma;
+  dma.init(wave, lane, ld);
+  // ---- producer: step ps of item P goes into slot pslot (4 LDS-DMA instructions per wave and step) ----
+  int pk = 0, ps = 0, pslot = 0, inflight = 0;  // inflight: steps issued and not yet waited for
+  Fwd4Item P = load_item(0);
+  auto produce = [&]() {
+    if (!P.valid) return;
+    const uint16_t* base = (ABL & 128) ? qkv : qkv + (int64_t)P.b * T * ld + P.h * HD;  // 128: every step from the same (cache-resident) rows
+    char* dst = smem + pslot * 2 * TILE;
+    if (!(ABL & 16)) {
+      int row0, row1, col;
+      if (ps < 2) {  // Q rows [128 ps, 128 ps + 128) of the tile
+        row0 = (ABL & 128) ? 0 : P.q0 + 128 * ps;
+        row1 = row0 + 64;
+        col = 0;
+      } else {       // K | V tile
+        row0 = row1 = (ABL & 128) ? 0 : (P.jt_lo + ps - 2) * KT;
+        col = dm;
+      }
+      const uint16_t* s0 = base + (int64_t)row0 * ld + col;
+      const uint16_t* s1 = base + (int64_t)row1 * ld + (ps < 2 ? 0 : 2 * dm);
+      if (row1 + KT <= T) {
+        dma.issue_full(dst, s0, wave);
+        dma.issue_full(dst + TILE, s1, wave);
+      } else {  // rows beyond T are clamped to the last row (their products are masked or never stored)
+        dma.issue(dst, base + col, ld, T - 1, wave, row0);
+        dma.issue(dst + TILE, base + (ps < 2 ? 0 : 2 * dm), ld, T - 1, wave, row1);
+      }
+      if (HAS_DOC && ps == 0 && wave == 0) {  // the item's 256 doc starts (one 1 KiB piece; T % 4 == 0 is checked on the host)
+        const int q = min(P.q0 + lane * 4, T - 4);
+        dma16_asm(doc_start + (int64_t)P.b * T + q, reinterpret_cast<char*>(dstage + (pk & 1) * 256));
+      }
+    }
+    ++inflight;
+    pslot = (pslot + 1 == NST) ? 0 : pslot + 1;
+    const int ns = 2 + P.jt_hi - P.jt_lo;
+    if (++ps == ns) {
+      ps = 0;
+      P = load_item(++pk);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) produce();
+
+  // ---- consumer ----
+  int cslot = 0, store_credit = 0;
+  auto sync_step = [&]() {
+    // Wait for this wave's pieces of the oldest step in flight; the younger steps (at most NST - 2) stay in flight, and so do the 10
+    // stores of the previous item's epilogue while they are younger than the awaited step (vmcnt counts loads and stores in issue order;
+    // without the allowance every item would wait for its predecessor's O rows to reach memory).
+    const int younger = inflight - 1;
+    if (store_credit > 0) {
+      --store_credit;
+      if (NST >= 4 && younger >= 2) attn_wait_vm<18>();
+      else if (NST >= 3 && younger == 1) attn_wait_vm<14>();
+      else attn_wait_vm<10>();
+    } else {
+      if (NST >= 4 && younger >= 2) attn_wait_vm<8>();
+      else if (NST >= 3 && younger == 1) attn_wait_vm<4>();
+      else attn_wait_vm<0>();
+    }
+    --inflight;
+    if (!(ABL & 32)) attn_barrier();  // everyone's pieces landed; and every wave is done with the previous step, whose slot is refilled now
+    produce();
+  };
+  auto next_slot = [&]() { cslot = (cslot + 1 == NST) ? 0 : cslot + 1; };
+
+  bf16x8_t qf[2][4];
+  int dsq[2];
+  f32x16_t o[2][2];
+  float mc[2], lsum[2];  // running reference maximum in log2 units (s * c2), running sum
+  int r0[2];             // first rows of this wave's two blocks (wave-uniform)
+
+  // one row block's softmax + P V for one tile (s: its S^T accumulators, vfr: the tile's V fragments)
+  auto soft_pv = [&](int qb_, f32x16_t (&s)[2], const bf16x8_t (&vfr)[2][4], int kv0, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const int qb = qb_;
+    if (ABL & 64) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          f32x4_t t4 = {s[sp >> 1][(sp & 1) * 8], s[sp >> 1][(sp & 1) * 8 + 1], s[sp >> 1][(sp & 1) * 8 + 2], s[sp >> 1][(sp & 1) * 8 + 3]};
+          const bf16x8_t pq = __builtin_bit_cast(bf16x8_t, t4);
+          if (ABL & 4)
+            asm volatile("" : "+v"(o[qb][db]) : "v"(vfr[db][sp]), "v"(pq));
+          else
+            o[qb][db] = mfma32(vfr[db][sp], pq, o[qb][db]);
+        }
+      return;
+    }
+    // key (kb, r) of this lane is tile row kb*32 + (r&3) + 8*(r>>2) + 4*hi: visible iff  c_lo <= kb*32 + (r&3) + 8*(r>>2) <= c_hi
+    const int c_hi = r0[qb] + l31 - kv0 - 4 * hi;
+    const int c_lo = HAS_DOC ? dsq[qb] - kv0 - 4 * hi : 0;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+          const bool ok = (c <= c_hi) && (!HAS_DOC || c >= c_lo);
+          if (!ok) s[kb][r] = -INFINITY;
+        }
+        tmax = fmaxf(tmax, s[kb][r]);
+      }
+    {
+      float t_lo, t_hi;
+      half_pair(tmax, t_lo, t_hi);
+      tmax = fmaxf(t_lo, t_hi);
+    }
+    const float tm = tmax * c2;
+    const bool need = tm > mc[qb] + ATTN_DEFER_LOG2;  // both -inf (nothing visible yet): false
+    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {   // wave-uniform and rare after the first tile
+      const float mn = fmaxf(mc[qb], tm);
+      const float alpha = fast_exp2(mc[qb] - ((mn == -INFINITY) ? 0.f : mn));
+      mc[qb] = mn;
+      lsum[qb] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+    }
+    const float mref = (MASK && mc[qb] == -INFINITY) ? 0.f : mc[qb];
+    float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float px = __builtin_fmaf(s[kb][r], c2, -mref);
+        const float p = (ABL & 1) ? px : fast_exp2(px);
+        ps4[r & 3] += p;
+        pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
+      }
+    lsum[qb] += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        if (ABL & 4)
+          asm volatile("" : "+v"(o[qb][db]) : "v"(vfr[db][sp]), "v"(pf[sp]));
+        else
+          o[qb][db] = mfma32(vfr[db][sp], pf[sp], o[qb][db]);
+      }
+  };
+
+  // one KV tile: S^T = K Q^T for the active row blocks, then softmax + P V per block.  M0 / M1: mode of block 0 / 1.
+  auto compute = [&](int kv0, const char* sK, const char* sV, auto m0_tag, auto m1_tag) {
+    constexpr int M0 = decltype(m0_tag)::value, M1 = decltype(m1_tag)::value;
+    bf16x8_t kfr[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kfr[kb][ks] = (ABL & 8) ? qf[0][ks] : frag_rows(sK, kb * 32 + l31, ks, hi);
+        if (ABL & 8) asm volatile("" : "+v"(kfr[kb][ks]));
+      }
+    f32x16_t s[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if ((qb == 0 ? M0 : M1) == QB_OFF) continue;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        zero16(s[qb][kb]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ABL & 2)
+            asm volatile("" : "+v"(s[qb][kb]) : "v"(kfr[kb][ks]));
+          else
+            s[qb][kb] = mfma32(kfr[kb][ks], qf[qb][ks], s[qb][kb]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // 256 registers: keep the V fragments out of the Q K^T phase
+    bf16x8_t vfr[2][4];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        vfr[db][sp] = (ABL & 8) ? qf[0][sp] : frag_cols(sV, db, (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi, lane);
+        if (ABL & 8) asm volatile("" : "+v"(vfr[db][sp]));
+      }
+    if (M0 == QB_UM) soft_pv(0, s[0], vfr, kv0, std::false_type{});
+    if (M0 == QB_MASK) soft_pv(0, s[0], vfr, kv0, std::true_type{});
+    if (M1 == QB_UM) soft_pv(1, s[1], vfr, kv0, std::false_type{});
+    if (M1 == QB_MASK) soft_pv(1, s[1], vfr, kv0, std::true_type{});
+  };
+
+  using OFF_ = std::integral_constant<int, QB_OFF>;
+  using UM_ = std::integral_constant<int, QB_UM>;
+  using MK_ = std::integral_constant<int, QB_MASK>;
+
+  for (int ck = 0;; ++ck) {
+    const Fwd4Item C = load_item(ck);
+    if (!C.valid) break;
+    r0[0] = C.q0 + 32 * wave;
+    r0[1] = C.q0 + 32 * (7 - wave);
+    if (wave == 0) {  // the id of item ck + 2 (ids[(ck + 1) & 3] was fetched during the previous item)
+      if (ck == 0 || __builtin_amdgcn_readfirstlane(ids[(ck + 1) & 3]) < n_items) {
+        store_credit = 0;  // the atomic's own wait drains everything
+        fetch_id(ck + 2);
+      } else if (lane == 0) {
+        ids[(ck + 2) & 3] = n_items;
+      }
+    }
+    // ---- steps 0, 1: this wave's Q blocks out of the ring (block bi of the tile: half bi / 4, 64-row tile (bi & 3) / 2, rows 32 (bi & 1)..) ----
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      sync_step();
+      const int bi = (qb == 0 ? wave : 7 - wave) & 3;
+      const char* tq = smem + cslot * 2 * TILE + (bi >> 1) * TILE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = frag_rows(tq, (bi & 1) * 32 + l31, ks, hi);
+      dsq[qb] = 0;
+      if (HAS_DOC) dsq[qb] = dstage[(ck & 1) * 256 + (r0[qb] - C.q0) + l31];  // landed with step 0 (wave 0 waited for it, then the barrier)
+      zero16(o[qb][0]);
+      zero16(o[qb][1]);
+      mc[qb] = -INFINITY;
+      lsum[qb] = 0.f;
+      next_slot();
+    }
+    // ---- K | V tiles ----
+    int jt = C.jt_lo;
+    auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
+      for (; jt < jt_end; ++jt) {
+        sync_step();
+        if (active) compute(jt * KT, smem + cslot * 2 * TILE, smem + cslot * 2 * TILE + TILE, m0_tag, m1_tag);
+        next_slot();
+      }
+    };
+    // block qb: tiles [0, r0/64) need no mask, tile r0/64 holds its diagonal, later tiles are above it; rows beyond T compute on clamped rows
+    const int a0 = min(C.jt_hi, r0[0] / KT), e0 = min(C.jt_hi, r0[0] / KT + 1);
+    const int a1 = min(C.jt_hi, r0[1] / KT), e1 = min(C.jt_hi, r0[1] / KT + 1);
+    if (HAS_DOC) {
+      run(e0, MK_{}, MK_{}, true);
+      run(e1, OFF_{}, MK_{}, true);
+    } else {
+      run(a0, UM_{}, UM_{}, true);
+      run(e0, MK_{}, UM_{}, true);
+      run(a1, OFF_{}, UM_{}, true);
+      run(e1, OFF_{}, MK_{}, true);
+    }
+    run(C.jt_hi, OFF_{}, OFF_{}, false);
+    // ---- epilogue: O rows through the wave's LDS staging area as whole 128-byte rows; nobody waits for the stores ----
+    char* const ost = ostage + wave * OST;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float l_lo, l_hi;
+      half_pair(lsum[qb], l_lo, l_hi);
+      const float ltot = l_lo + l_hi;
+      const float inv = 1.f / ltot;
+      // lane (l31, hi) holds row l31, head dims db*32 + 8g + 4hi + e: 8-byte piece `hi` of the 16-byte chunk c16 = 4 db + g, stored at
+      // chunk position c16 ^ (row & 7) (spreads a column of chunks over the banks)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          bf16x4_t v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[qb][db][4 * gq + e] * inv);
+          *reinterpret_cast<bf16x4_t*>(ost + l31 * 128 + (((db * 4 + gq) ^ (l31 & 7)) << 4) + hi * 8) = v;
+        }
+      const int qrow = r0[qb] + l31;
+      if (ABL & 256) continue;
+      if (qrow < T && hi == 0) lse[((int64_t)C.b * nh + C.h) * T + qrow] = mc[qb] + __builtin_amdgcn_logf(ltot);  // base-2 LSE
+      // read back: lane L takes chunk L & 7 of rows L >> 3, + 8, + 16, + 24 (same wave wrote them: no barrier, the compiler's lgkmcnt orders it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), c16 = lane & 7;
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(ost + row * 128 + ((c16 ^ (row & 7)) << 4));
+        const int orow = r0[qb] + row;
+        if (orow < T) st_bf16x8(out + ((int64_t)C.b * T + orow) * dm + C.h * HD + c16 * 8, v);
+      }
+    }
+    store_credit = (C.q0 + QB <= T && !(ABL & 256)) ? NST - 1 : 0;  // all 10 store instructions were issued by every wave
+  }
+  // the last workgroup out resets the scheduler for the next launch (launches of this kernel on one device must not overlap)
+  if (t == 0 && atomicAdd(sched + 1, 1u) == (unsigned)(G - 1)) {
+    sched[0] = 0;
+    sched[1] = 0;
+  }
+}
+
+// =============================================================================================
 // backward: dQ  (one workgroup = 4 waves x (32 * NQB) query rows; key tiles of 64 rows; q, k rotated)
 // Also computes delta[q] = sum_d dO[q][d] O[q][d] for its rows and publishes it for the dK/dV kernel, which runs after it.
 // =============================================================================================
@@ -914,6 +1259,31 @@ static void launch_fwd3(const uint16_t* qkv, const int32_t* doc_start, uint16_t*
   else
     hipLaunchKernelGGL((attn_fwd3_kernel<false, NST, MINW, ABL>), grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
 }
+static int attn_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+__device__ unsigned g_attn_sched[8];  // {next item, finished workgroups} per kernel family: forward, dQ, dK/dV
+static unsigned* attn_sched(int family) {
+  static unsigned* base = nullptr;
+  if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_attn_sched)) != hipSuccess) base = nullptr;
+  return base + 2 * family;
+}
+template <int NST, int ABL = 0>
+static void launch_fwd4(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
+  const int n_items = (int)(plm_cdiv(T, 256) * nh * B);
+  const int G = n_items < 2 * attn_num_cus() ? n_items : 2 * attn_num_cus();
+  const dim3 grid((unsigned)G), block(256);
+  if (doc_start && ABL == 0)
+    hipLaunchKernelGGL((attn_fwd4_kernel<true, NST, 0>), grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh, (int)(nh * B), n_items, attn_sched(0));
+  else
+    hipLaunchKernelGGL((attn_fwd4_kernel<false, NST, ABL>), grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh, (int)(nh * B), n_items, attn_sched(0));
+}
 template <int NB, int MINW>
 static void launch_dq2(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
                        const float* rs, const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
@@ -940,6 +1310,15 @@ void plm_attn_fwd2(int variant, const uint16_t* qkv, const int32_t* doc_start, u
   switch (variant) {
     case 21: launch_fwd2<2, 1>(qkv, doc_start, out, lse, B, T, nh, s); break;
     case 12: launch_fwd2<1, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 43: launch_fwd4<3>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 44: launch_fwd4<4>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 3243: launch_fwd4<3, 32>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 1643: launch_fwd4<3, 16>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 6443: launch_fwd4<3, 64>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 12643: launch_fwd4<3, 126>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 12843: launch_fwd4<3, 128>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 25643: launch_fwd4<3, 256>(qkv, doc_start, out, lse, B, T, nh, s); break;
+    case 38443: launch_fwd4<3, 384>(qkv, doc_start, out, lse, B, T, nh, s); break;
     case 32: launch_fwd3<2, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
     case 33: launch_fwd3<3, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;
     case 34: launch_fwd3<4, 2>(qkv, doc_start, out, lse, B, T, nh, s); break;

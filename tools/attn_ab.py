@@ -38,11 +38,12 @@ def main():
   ap.add_argument('--B', type=int, default=32)
   ap.add_argument('--T', type=int, default=1024)
   ap.add_argument('--nh', type=int, default=12)
-  ap.add_argument('--iters', type=int, default=20)
+  ap.add_argument('--iters', type=int, default=40)
   ap.add_argument('--fwd', default='0,22,21,12')
   ap.add_argument('--dq', default='0,22,21,12')
   ap.add_argument('--dkdv', default='0,21')
   ap.add_argument('--doc', action='store_true')
+  ap.add_argument('--reps', type=int, default=3, help='passes over the forward variants; the best time of each is reported')
   a = ap.parse_args()
   dev = 'cuda'
   B, T, nh = a.B, a.T, a.nh
@@ -76,10 +77,19 @@ def main():
   out0, lse0 = ops.attn_fwd(qkv, B, T, nh, ds)
   dqkv0 = ops.attn_bwd(qkv, out0, dout, lse0, cos, sin, B, T, nh, ds)
   torch.cuda.synchronize()
-  for f in [int(x) for x in a.fwd.split(',') if x]:
+  for _ in range(300):  # clocks / power state settle over ~50 ms of load: the first variants of a cold run read 10 % slow
+    ops.attn_fwd(qkv, B, T, nh, ds)
+  fv = [int(x) for x in a.fwd.split(',') if x]
+  best = {}
+  for rep in range(a.reps):
+    for f in fv:
+      setv(f, 0, 0)
+      us = timeit(lambda: ops.attn_fwd(qkv, B, T, nh, ds), a.iters)
+      best[f] = min(best.get(f, 1e9), us)
+  for f in fv:
     setv(f, 0, 0)
     out, lse = ops.attn_fwd(qkv, B, T, nh, ds)
-    us = timeit(lambda: ops.attn_fwd(qkv, B, T, nh, ds), a.iters)
+    us = best[f]
     print(f'fwd variant {f:2d}: {us:7.1f} us  {fl / us / 1e6:6.0f} TFLOP/s   out vs v0 {relmax(out, out0):.2e}  lse max|diff| {(lse - lse0).abs().max().item():.2e}', flush=True)
   for q in [int(x) for x in a.dq.split(',') if x]:
     setv(0, q, 0)
