@@ -1,31 +1,32 @@
-// Flash-style causal / document-masked attention for gfx950 with RoPE applied in-kernel.
-// Replaces models/transformer.py:43-65 (split, RoPE, transposes, SDPA, transpose back) and
-// models/embeddings.py:15-30; the mask of data/datasets/data_prep_utils.py:7-23 is expressed as
-// doc_start[B,T] (query i sees key j iff doc_start[i] <= j <= i; doc_start is non-decreasing in i).
+// Flash-style attention for gfx950 with RoPE applied in-kernel: the C ABI, the stand-alone RoPE pass, and the kernels that serve
+// batches WITH document masks (causal batches without a mask take the kernels of attn_causal.hip).
+// Replaces models/transformer.py:43-65 (split, RoPE, transposes, SDPA, transpose back) and models/embeddings.py:15-30; the mask of
+// data/datasets/data_prep_utils.py:7-23 is expressed as doc_start[B,T] (query i sees key j iff doc_start[i] <= j <= i; doc_start is
+// non-decreasing in i).
 //
-// q, k, v are read strided straight out of the w_qkv output [B*T, 3*nh*64]; no transposed copies.
-// All matrix products are v_mfma_f32_32x32x16_bf16.  Scores are computed TRANSPOSED
-// (S^T[kv][q] = K·Q^T) so a lane owns one query column: row max / row sum are in-lane plus one
-// cross-half shuffle, and the probabilities are already in the B-operand layout of the following
-// P·V product (no LDS round trip for P).  The V / K / Q / dO operands whose contraction index is the
-// token row are fetched with ds_read_b64_tr_b16 (hardware transpose) from the same LDS image that
-// serves the ds_read_b128 operands.
+// q, k, v are read strided straight out of the w_qkv output [B*T, 3*nh*64]; no transposed copies.  All matrix products are
+// v_mfma_f32_32x32x16_bf16.  Scores are computed TRANSPOSED (S^T[kv][q] = K Q^T) so a lane owns one query column: row max / row sum are
+// in-lane plus one cross-half shuffle, and the probabilities are already in the B-operand layout of the following P V product (no LDS
+// round trip for P).  The V / K / Q / dO operands whose contraction index is the token row are fetched with ds_read_b64_tr_b16 (hardware
+// transpose) from the same LDS image that serves the ds_read_b128 operands.
 //
-// RoPE is applied ONCE per layer to the q|k blocks of the projection output (rope_qk_kernel, in place), so no
-// inner loop rotates anything; K/V (fwd, dQ) and Q/dO (dK/dV) tiles are staged global -> LDS by LDS-DMA into
-// two LDS stages with one barrier per tile (no VGPR round trip, no ds_write); the backward kernels apply the
-// inverse rotation to dQ / dK in their epilogues, so dqkv is the gradient w.r.t. the PRE-rotation projection.
+// q and k arrive ROTATED (the w_qkv GEMM's epilogue applies RoPE, plm_qkv_rope_bf16; rope_qk_kernel below is that entry point's fallback
+// and the tests' yardstick), so no inner loop rotates anything; K / V (fwd, dQ) and Q / dO (dK/dV) tiles are staged global -> LDS by LDS-DMA
+// (no VGPR round trip, no ds_write); the backward kernels apply the inverse rotation to dQ / dK in their epilogues, so dqkv is the gradient
+// w.r.t. the PRE-rotation projection.
+//
+// Kernels for document masks: 128-row tiles (4 waves x 32 rows, up to 4 workgroups per CU), 64-row K / V (Q / dO) tiles through two LDS
+// stages; tiles that lie entirely before the first document of a workgroup's rows (or after its last) are skipped, every processed tile
+// takes the masked softmax.  With documents of a few hundred tokens most tiles are skipped, which is why these kernels - not the
+// 256-row causal ones - serve this case (profiles/r03_attn_ablation.txt: 62 vs 86 us forward at mean document length 256).
 #include "plm_device.h"
-
-#include <type_traits>
 
 #include "attn_common.h"
 
 // =============================================================================================
 // RoPE on the q and k column blocks of the w_qkv output, in place (models/embeddings.py:15-30):
 // interleaved pairs (x[2i], x[2i+1]) -> (a cos - b sin, b cos + a sin), fp32 math, bf16 result.
-// Runs once per layer right after the projection, so no inner loop ever rotates anything again
-// (the backward kernels apply the inverse rotation to dQ / dK in their epilogues).
+// The fallback of plm_qkv_rope_bf16 (shapes its fused epilogue does not take) and the yardstick of the epilogue's bit-equality tests.
 // =============================================================================================
 __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
                                                       const float* __restrict__ rsin, int64_t BT, int T, int nh) {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv
 }
 
 // =============================================================================================
-// forward (q, k already rotated)
+// forward with document masks (q, k already rotated)
 // =============================================================================================
 // Block -> (128-row tile, head, batch).  A causal tile's work grows linearly with its index (2 .. 2*T/128 key tiles), and the
 // hardware hands blocks out in blockIdx order, so the order is tile-major: ALL blocks of the heaviest tile index first,
@@ -62,8 +63,7 @@ __device__ __forceinline__ void attn_block(int T, int nh, int& tile, int& h, int
   b = bh / nh;
 }
 
-template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
+__global__ __launch_bounds__(256, 4) void attn_fwd_doc_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
   constexpr int KT = 64;            // kv rows per tile
   constexpr int TILE = KT * 128;    // 8 KiB
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
   for (int ks = 0; ks < 4; ++ks)
     qf[ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
   int dsq = 0;
-  if (HAS_DOC && qvalid) dsq = doc_start[(int64_t)b * T + qrow];
+  if (qvalid) dsq = doc_start[(int64_t)b * T + qrow];
   asm volatile("; q fragments resident" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(dsq));  // consumed before any DMA is in flight
 
   f32x16_t o[2];
@@ -99,8 +99,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
 
   const int kv_hi = min(T, q0 + 128);
   const int jt_hi = (kv_hi + KT - 1) / KT;
-  int jt_lo = 0;
-  if (HAS_DOC) jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
+  const int jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;  // tiles before the first row's document: skipped
 
   TileDma dma;
   dma.init(wave, lane, ld);
@@ -116,9 +115,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
     }
   };
 
-  // one KV tile: S^T = K Q^T, online softmax (masked or not), O^T += V^T P^T
-  auto tile_body = [&](int jt, int st, auto mask_tag) {
-    constexpr bool MASK = decltype(mask_tag)::value;
+  // one KV tile: S^T = K Q^T, masked online softmax, O^T += V^T P^T
+  auto tile_body = [&](int jt, int st) {
     const int kv0 = jt * KT;
     if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
     const char* sK = smem + st * 2 * TILE;
@@ -136,11 +134,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (MASK) {
-            const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
-            const bool ok = (kvg <= qrow) && (!HAS_DOC || kvg >= dsq);
-            if (!ok) s[kb][r] = -INFINITY;
-          }
+          const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+          if (!((kvg <= qrow) && (kvg >= dsq))) s[kb][r] = -INFINITY;
           tmax = fmaxf(tmax, s[kb][r]);
         }
       }
@@ -189,12 +184,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
   if (jt_lo < jt_hi) stage(0, jt_lo);
   attn_wait_vm<0>();
   attn_barrier();
-  // Tiles strictly below the block's first query row need no mask (pure causal): run them in their own loop so the
-  // mask code does not inflate the register allocation of the hot loop; the last tiles touch the diagonal.
-  const int jt_diag = HAS_DOC ? jt_lo : max(jt_lo, min(jt_hi, q0 / KT));
   int st = 0;
-  for (int jt = jt_lo; jt < jt_diag; ++jt, st ^= 1) tile_body(jt, st, std::false_type{});
-  for (int jt = jt_diag; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st, std::true_type{});
+  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st);
 
   float l_lo, l_hi;
   half_pair(lsum, l_lo, l_hi);
@@ -217,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
 }
 
 // =============================================================================================
-// backward: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows; q, k rotated)
+// backward with document masks: dK, dV  (one workgroup per 128 key rows; loops over query tiles of 64 rows; q, k rotated)
 //
 // Why the backward stays two passes of 4-wave workgroups (round 2, profiles/r02_ubench_overlap.txt, r02_pmc_sq.txt):
 // the kernels are bound by instruction issue and LDS reads, not by the matrix pipe (27 % busy) - per 32x32 block a wave
@@ -229,8 +220,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const uint16_t* __rest
 // block.  A single-pass kernel (dQ with dK / dV from one recomputation) saves 8 of 28 MFMAs per block but has to move
 // ~0.44 GB of fp32 dQ partials per layer through HBM twice to stay deterministic - no gain while the MFMAs are not the limit.
 // =============================================================================================
-template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_doc_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                                const int32_t* __restrict__ doc_start, uint16_t* __restrict__ dqkv,
@@ -254,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
   const float* lrow = lse + ((int64_t)b * nh + h) * T;
   const float* drow = delta + ((int64_t)b * nh + h) * T;
-  const int32_t* dsrow = doc_start + (HAS_DOC ? (int64_t)b * T : 0);
+  const int32_t* dsrow = doc_start + (int64_t)b * T;
   const float scale = 0.125f, c2 = scale * LOG2E;
 
   bf16x8_t kf[4], vf[4];
@@ -268,11 +258,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   // after this key block (doc_start is non-decreasing)
   const int nqt = (T + QT - 1) / QT;
   const int jq_lo = kv0 / QT;
-  int jq_hi = nqt;
-  if (HAS_DOC) {
-    jq_hi = jq_lo;
-    while (jq_hi < nqt && __builtin_amdgcn_readfirstlane(dsrow[jq_hi * QT]) <= kv0 + 127) ++jq_hi;
-  }
+  int jq_hi = jq_lo;
+  while (jq_hi < nqt && __builtin_amdgcn_readfirstlane(dsrow[jq_hi * QT]) <= kv0 + 127) ++jq_hi;
   asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
                "v"(vf[3]));  // every ordinary load is consumed before the first DMA is in flight
 
@@ -296,12 +283,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
       const int q = min(qt0 + lane * 4, T - 4);
       dma16_asm(lrow + q, dst + 2 * TILE);
       dma16_asm(drow + q, dst + 2 * TILE + 256);
-      if (HAS_DOC) dma16_asm(dsrow + q, dst + 2 * TILE + 512);
+      dma16_asm(dsrow + q, dst + 2 * TILE + 512);
     }
   };
 
-  auto tile_body = [&](int jq, int st, auto mask_tag) {
-    constexpr bool MASK = decltype(mask_tag)::value;
+  auto tile_body = [&](int jq, int st) {
     const int qt0 = jq * QT;
     if (jq + 1 < jq_hi) stage(st ^ 1, jq + 1);
     const char* sQ = smem + st * STAGE;
@@ -327,21 +313,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
           const int ql0 = qb * 32 + 8 * g + 4 * hi;
           const f32x4_t L4 = *reinterpret_cast<const f32x4_t*>(sL + ql0);  // base-2 LSE
           const f32x4_t D4 = *reinterpret_cast<const f32x4_t*>(sD + ql0);
-          int ds4[4] = {0, 0, 0, 0};
-          if (MASK && HAS_DOC) {
+          int ds4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ds4[e] = sDS[ql0 + e];
-          }
+          for (int e = 0; e < 4; ++e) ds4[e] = sDS[ql0 + e];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             float p = fast_exp2(__builtin_fmaf(s[r], c2, -L4[e]));  // explicit fma: hipcc otherwise pairs s*c2 with lse*LOG2E in a v_pk_mul (16 v_mov per block)
-            if (MASK) {
-              const int qg = qt0 + ql0 + e;
-              bool ok = (kvrow <= qg) && (qg < T);
-              if (HAS_DOC) ok = ok && (kvrow >= ds4[e]);
-              p = ok ? p : 0.f;
-            }
+            const int qg = qt0 + ql0 + e;
+            p = ((kvrow <= qg) && (qg < T) && (kvrow >= ds4[e])) ? p : 0.f;
             const float dsv = p * (dp[r] - D4[e]);  // the 1/sqrt(hd) factor (a power of two: exact) is applied once, to dK, in the epilogue
             pf[r >> 3][r & 7] = f2bf(p);
             dsf[r >> 3][r & 7] = f2bf(dsv);
@@ -365,14 +345,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
   if (jq_lo < jq_hi) stage(0, jq_lo);
   attn_wait_vm<0>();
   attn_barrier();
-  // three segments so the mask code stays out of the hot loop: the two tiles on the diagonal of this key block,
-  // the tiles entirely below it (pure causal: unmasked), and a last partial tile when T % 64 != 0
-  const int jq_d = min(jq_hi, jq_lo + 2);
-  const int jq_u = HAS_DOC ? jq_d : max(jq_d, min(jq_hi, T / QT));
-  int st = 0, jq = jq_lo;
-  for (; jq < jq_d; ++jq, st ^= 1) tile_body(jq, st, std::true_type{});
-  for (; jq < jq_u; ++jq, st ^= 1) tile_body(jq, st, std::false_type{});
-  for (; jq < jq_hi; ++jq, st ^= 1) tile_body(jq, st, std::true_type{});
+  int st = 0;
+  for (int jq = jq_lo; jq < jq_hi; ++jq, st ^= 1) tile_body(jq, st);
 
   if (kvalid) {
     uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
@@ -402,10 +376,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const uint16_t* _
 }
 
 // =============================================================================================
-// backward: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows; q, k rotated)
+// backward with document masks: dQ  (one workgroup per 128 query rows; loops over key tiles of 64 rows; q, k rotated)
 // =============================================================================================
-template <bool HAS_DOC>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_doc_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                              const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta,
                                                              const float* __restrict__ rcos, const float* __restrict__ rsin,
@@ -449,7 +422,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       for (int e = 0; e < 8; ++e) part += bf2f(o8[e]) * bf2f(dof[ks][e]);
     }
     Dq = part;
-    if (HAS_DOC) dsq = doc_start[(int64_t)b * T + qrow];
+    dsq = doc_start[(int64_t)b * T + qrow];
   }
   {
     float d_lo, d_hi;
@@ -459,8 +432,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   }
   const int kv_hi = min(T, q0 + 128);
   const int jt_hi = (kv_hi + KT - 1) / KT;
-  int jt_lo = 0;
-  if (HAS_DOC) jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
+  const int jt_lo = __builtin_amdgcn_readfirstlane(doc_start[(int64_t)b * T + q0]) / KT;
   asm volatile("; q/dO fragments resident" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(dof[0]), "v"(dof[1]), "v"(dof[2]),
                "v"(dof[3]), "v"(Lq), "v"(Dq), "v"(dsq));
 
@@ -482,8 +454,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     }
   };
 
-  auto tile_body = [&](int jt, int st, auto mask_tag) {
-    constexpr bool MASK = decltype(mask_tag)::value;
+  auto tile_body = [&](int jt, int st) {
     const int kv0 = jt * KT;
     if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
     const char* sK = smem + st * 2 * TILE;
@@ -503,12 +474,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = fast_exp2(__builtin_fmaf(s[r], c2, -Lq));
-          if (MASK) {
-            const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
-            bool ok = (kvg <= qrow);
-            if (HAS_DOC) ok = ok && (kvg >= dsq);
-            p = ok ? p : 0.f;
-          }
+          const int kvg = kv0 + kb * 32 + mfma32_row(r, hi);
+          p = ((kvg <= qrow) && (kvg >= dsq)) ? p : 0.f;
           dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq));  // x 1/sqrt(hd) once, in the epilogue
         }
 #pragma unroll
@@ -526,10 +493,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   if (jt_lo < jt_hi) stage(0, jt_lo);
   attn_wait_vm<0>();
   attn_barrier();
-  const int jt_diag = HAS_DOC ? jt_lo : max(jt_lo, min(jt_hi, q0 / KT));  // tiles below q0 need no mask
   int st = 0;
-  for (int jt = jt_lo; jt < jt_diag; ++jt, st ^= 1) tile_body(jt, st, std::false_type{});
-  for (int jt = jt_diag; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st, std::true_type{});
+  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st);
 
   if (qvalid) {
     uint16_t* dqp = dqkv + ((int64_t)b * T + qrow) * ld + h * HD;
@@ -555,13 +520,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 // =============================================================================================
 // C ABI
 // =============================================================================================
-// second-generation kernels (attn_v2.hip); variant 0 = the first-generation kernels of this file
-void plm_attn_fwd2(int variant, const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s);
-void plm_attn_dq2(int variant, const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
-                  const float* rs, const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);
-void plm_attn_dkdv2(int variant, const uint16_t* qkv, const uint16_t* dout, const float* lse, const float* delta, const float* rc,
-                    const float* rs, const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);
-static int attn_variant(int env_value, int dflt) { return env_value >= 0 ? env_value : dflt; }
+// causal batches (no document mask): attn_causal.hip
+void plm_attn_fwd_causal(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s);
+void plm_attn_bwd_causal(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
+                         const float* rs, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);
 
 static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, int64_t hd) {
   PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
@@ -589,15 +551,12 @@ extern "C" int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint1
   if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
   const dim3 grid((unsigned)(plm_cdiv(T, 128) * nh * B)), block(256);  // see attn_block
   hipStream_t s = (hipStream_t)stream;
-  if (const int v = attn_variant(plm_env().attn_fwd, 22)) {
-    plm_attn_fwd2(v, qkv, doc_start, out, lse, B, T, nh, s);
+  if (!doc_start) {
+    plm_attn_fwd_causal(qkv, out, lse, B, T, nh, s);
     PLM_CHECK_LAUNCH("plm_attn_fwd");
     return PLM_OK;
   }
-  if (doc_start)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
+  hipLaunchKernelGGL(attn_fwd_doc_kernel, grid, block, 0, s, qkv, doc_start, out, lse, (int)T, (int)nh);
   PLM_CHECK_LAUNCH("plm_attn_fwd");
   return PLM_OK;
 }
@@ -611,19 +570,12 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   const dim3 block(256);
   // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
   const dim3 gkv((unsigned)(plm_cdiv(T, 128) * nh * B));
-  const int vq = attn_variant(plm_env().attn_dq, 22), vk = attn_variant(plm_env().attn_dkdv, 21);
-  if (vq)
-    plm_attn_dq2(vq, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, B, T, nh, s);
-  else if (doc_start)
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-  else
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-  if (vk)
-    plm_attn_dkdv2(vk, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, B, T, nh, s);
-  else if (doc_start)
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
-  else
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+  if (!doc_start) {
+    plm_attn_bwd_causal(qkv, out, dout, lse, delta, rope_cos, rope_sin, dqkv, B, T, nh, s);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_doc_kernel, gkv, block, 0, s, qkv, out, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+    hipLaunchKernelGGL(attn_bwd_dkdv_doc_kernel, gkv, block, 0, s, qkv, dout, lse, delta, rope_cos, rope_sin, doc_start, dqkv, (int)T, (int)nh);
+  }
   PLM_CHECK_LAUNCH("plm_attn_bwd");
   return PLM_OK;
 }

@@ -1,0 +1,641 @@
+// Causal attention (no document masks) for gfx950, second generation of kernels: forward, backward dQ, backward dK / dV.
+// Same math, LDS image, LDS-DMA staging and C ABI as attn.hip (whose kernels keep serving document-masked batches: their 128-row
+// tiles skip more of a block-diagonal mask); q, k are already rotated (RoPE lives in the w_qkv GEMM's epilogue).
+//
+// What round 3 measured on the first-generation kernels (profiles/r03_attn_ablation.txt, r03_ubench_mfma_gap.txt: timing-only ablations, SQ counters,
+// tools/ubench/mfma_gap.hip) and what these kernels do about it:
+//   * Nothing overlapped: removing any one of {softmax arithmetic, MFMAs, LDS fragment reads, K / V DMA, barriers, Q loads + O stores} from the
+//     forward kernel saved that part's own time (35 / 21 / 16 / 33 / 15 / 30 of 106 us).  The waves are dependency chains  ds_read -> wait -> MFMA
+//     -> softmax -> MFMA, and with 2-4 waves per SIMD whose MFMA and VALU instructions share one issue port the SIMD sits at ~50 % of its
+//     MFMA + VALU time.  A wave here owns 64 rows (two 32-row blocks): every K / V (Q / dO) fragment read from LDS feeds two MFMAs, all
+//     fragments of a tile are requested up front, and one block's softmax arithmetic is scheduled beside the other block's MFMAs.
+//   * In a causal 256-row tile the waves of a workgroup had unequal work (rows 0-63 stop 3 key tiles before rows 192-255) and idled at the
+//     per-tile barrier: wave w now owns the 32-row blocks w and 7 - w - every wave does the same number of 32 x 64 blocks (forward and dQ).
+//   * K / V (Q / dO) tiles go through an NST-deep LDS ring filled NST - 1 tiles ahead with counted vmcnt waits instead of a double buffer.
+//   * The forward softmax defers the running-max update (the O rescale) until a row's maximum has grown by more than 2^8: with the exact
+//     maximum SOME row of a wave grows in almost every tile, so the "skip when nothing moved" test of generation one never skipped.
+//   * Mask code (diagonal tiles only) lives in separate per-wave loops; masks are two integer thresholds per lane and tile.
+// Measured (B = 32, T = 1024, 12 heads): forward 95 -> 88 us, dQ 139 -> 131 us, dK/dV 175 -> 167 us.  What did NOT work is recorded in
+// DESIGN.md section 5.3 (a persistent forward with one Q/K/V ring and a dynamic item queue; 64 key rows per wave at one wave per SIMD).
+#include "plm_device.h"
+
+#include <type_traits>
+
+#include "attn_common.h"
+
+// Block -> (row tile of RB rows, head, batch), heaviest (latest) tiles first: see attn_block() in attn.hip.
+template <int RB>
+__device__ __forceinline__ void attn_block2(int T, int nh, int& tile, int& h, int& b) {
+  const int ntile = (T + RB - 1) / RB;
+  const int nbh = gridDim.x / ntile;
+  const int bh = blockIdx.x % nbh;
+  tile = blockIdx.x / nbh;
+  h = bh % nh;
+  b = bh / nh;
+}
+
+#define ATTN_DEFER_LOG2 8.0f  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
+
+enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };  // a 32-row block on a key tile: above its diagonal / no mask needed / masked
+
+// =============================================================================================
+// forward: one workgroup = 4 waves x 64 query rows (256-row tiles), wave w owns the 32-row blocks w and 7 - w of the tile -
+// every wave of a causal tile then has the same amount of work (block w ends 7 - 2w blocks before block 7 - w) and no wave idles through
+// the diagonal region; K / V tiles of 64 rows go through an NST-deep LDS ring filled NST - 1 tiles ahead (counted vmcnt waits: the wait
+// in front of tile i only covers tile i), one barrier per tile.
+// Per tile a row block is OFF (tile above its diagonal), UM (no mask needed) or MASK.
+// =============================================================================================
+template <int NST>
+__global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                                 float* __restrict__ lse, int T, int nh) {
+  constexpr int KT = 64;
+  constexpr int TILE = KT * 128;  // 8 KiB
+  constexpr int QB = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];  // [stage][K|V]
+
+  int tile_, h, b;
+  attn_block2<QB>(T, nh, tile_, h, b);
+  const int qt = (T + QB - 1) / QB - 1 - tile_;
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int q0 = qt * QB;
+  const int r0[2] = {q0 + 32 * wave, q0 + 32 * (7 - wave)};  // first rows of this wave's two blocks
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const float c2 = 0.125f * LOG2E;  // 1/sqrt(64) and the base-2 exponent in one factor
+
+  bf16x8_t qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    const bool qvalid = qrow < T;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+    asm volatile("; q fragments resident" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]));  // consumed before any DMA is in flight
+
+  f32x16_t o[2][2];
+  float mc[2], lsum[2];  // running reference maximum in log2 units (s * c2), running sum
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    zero16(o[qb][0]);
+    zero16(o[qb][1]);
+    mc[qb] = -INFINITY;
+    lsum[qb] = 0.f;
+  }
+
+  const int kv_hi = min(T, q0 + QB);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  constexpr int jt_lo = 0;
+  const int n = jt_hi;
+
+  TileDma dma;
+  dma.init(wave, lane, ld);
+  auto stage = [&](int slot, int jt) {  // 4 LDS-DMA instructions per wave
+    const int kv0 = jt * KT;
+    const uint16_t* src = base + (int64_t)kv0 * ld;
+    if (kv0 + KT <= T) {  // whole tile inside the sequence (always, when T % 64 == 0): no per-lane address arithmetic
+      dma.issue_full(smem + slot * 2 * TILE, src + dm, wave);
+      dma.issue_full(smem + slot * 2 * TILE + TILE, src + 2 * dm, wave);
+    } else {
+      dma.issue(smem + slot * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+      dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    }
+  };
+
+  // one row block's softmax + P V for one tile (s: its S^T accumulators, vfr: the tile's V fragments)
+  auto soft_pv = [&](int qb_, f32x16_t (&s)[2], const bf16x8_t (&vfr)[2][4], int kv0, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const int qb = qb_;
+    // key (kb, r) of this lane is tile row kb*32 + (r&3) + 8*(r>>2) + 4*hi: visible iff  kb*32 + (r&3) + 8*(r>>2) <= c_hi
+    const int c_hi = r0[qb] + l31 - kv0 - 4 * hi;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+          if (c > c_hi) s[kb][r] = -INFINITY;
+        }
+        tmax = fmaxf(tmax, s[kb][r]);
+      }
+    {
+      float t_lo, t_hi;
+      half_pair(tmax, t_lo, t_hi);
+      tmax = fmaxf(t_lo, t_hi);
+    }
+    const float tm = tmax * c2;
+    const bool need = tm > mc[qb] + ATTN_DEFER_LOG2;  // both -inf (nothing visible yet): false
+    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {   // wave-uniform and rare after the first tile
+      const float mn = fmaxf(mc[qb], tm);
+      const float alpha = fast_exp2(mc[qb] - ((mn == -INFINITY) ? 0.f : mn));
+      mc[qb] = mn;
+      lsum[qb] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+    }
+    const float mref = (MASK && mc[qb] == -INFINITY) ? 0.f : mc[qb];
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(__builtin_fmaf(s[kb][r], c2, -mref));
+        ps[r & 3] += p;
+        pf[kb * 2 + (r >> 3)][r & 7] = f2bf(p);
+      }
+    lsum[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) o[qb][db] = mfma32(vfr[db][sp], pf[sp], o[qb][db]);
+  };
+
+  // one KV tile: S^T = K Q^T for the active row blocks, then softmax + P V per block.  M0 / M1: mode of block 0 / 1.
+  auto compute = [&](int kv0, const char* sK, const char* sV, auto m0_tag, auto m1_tag) {
+    constexpr int M0 = decltype(m0_tag)::value, M1 = decltype(m1_tag)::value;
+    bf16x8_t kfr[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kfr[kb][ks] = frag_rows(sK, kb * 32 + l31, ks, hi);
+    f32x16_t s[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if ((qb == 0 ? M0 : M1) == QB_OFF) continue;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        zero16(s[qb][kb]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[qb][kb] = mfma32(kfr[kb][ks], qf[qb][ks], s[qb][kb]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // 256 registers: keep the V fragments out of the Q K^T phase
+    bf16x8_t vfr[2][4];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) vfr[db][sp] = frag_cols(sV, db, (sp >> 1) * 32 + (sp & 1) * 16 + 4 * hi, lane);
+    if (M0 == QB_UM) soft_pv(0, s[0], vfr, kv0, std::false_type{});
+    if (M0 == QB_MASK) soft_pv(0, s[0], vfr, kv0, std::true_type{});
+    if (M1 == QB_UM) soft_pv(1, s[1], vfr, kv0, std::false_type{});
+    if (M1 == QB_MASK) soft_pv(1, s[1], vfr, kv0, std::true_type{});
+  };
+
+  // ring: tile i = jt - jt_lo lives in slot i % NST; tiles are issued NST - 1 ahead
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < n) stage(i, jt_lo + i);
+  int i = 0, slot = 0;
+  auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
+    for (; jt_lo + i < jt_end; ++i) {
+      // wait for this wave's pieces of tile i: the tiles issued after it (at most NST - 2, fewer at the end) may stay in flight
+      const int rem = min(NST - 2, n - 1 - i);
+      if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
+      else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+      else attn_wait_vm<0>();
+      attn_barrier();  // everyone's pieces landed; and every wave is done reading tile i - 1, whose slot is refilled now
+      if (i + NST - 1 < n) stage(slot == 0 ? NST - 1 : slot - 1, jt_lo + i + NST - 1);
+      if (active) compute((jt_lo + i) * KT, smem + slot * 2 * TILE, smem + slot * 2 * TILE + TILE, m0_tag, m1_tag);
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+    }
+  };
+  using OFF_ = std::integral_constant<int, QB_OFF>;
+  using UM_ = std::integral_constant<int, QB_UM>;
+  using MK_ = std::integral_constant<int, QB_MASK>;
+  // block qb: tiles [0, r0/64) need no mask, tile r0/64 holds its diagonal, later tiles are above it; rows beyond T compute on zeros
+  const int a0 = min(jt_hi, r0[0] / KT), e0 = min(jt_hi, r0[0] / KT + 1);
+  const int a1 = min(jt_hi, r0[1] / KT), e1 = min(jt_hi, r0[1] / KT + 1);
+  run(a0, UM_{}, UM_{}, true);
+  run(e0, MK_{}, UM_{}, true);
+  run(a1, OFF_{}, UM_{}, true);
+  run(e1, OFF_{}, MK_{}, true);
+  run(jt_hi, OFF_{}, OFF_{}, false);
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    float l_lo, l_hi;
+    half_pair(lsum[qb], l_lo, l_hi);
+    const float ltot = l_lo + l_hi;
+    if (qrow < T) {
+      const float inv = 1.f / ltot;
+      uint16_t* op = out + ((int64_t)b * T + qrow) * dm + h * HD;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4_t v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[qb][db][4 * g + e] * inv);
+          st_bf16x4(op + db * 32 + 8 * g + 4 * hi, v);
+        }
+      if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = mc[qb] + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
+    }
+  }
+}
+
+// =============================================================================================
+// backward dQ: 256-query tiles, wave w owns the 32-row blocks w and 7 - w (equal causal work), K | V tiles through an NST-deep
+// ring (see attn_fwd_causal_kernel).  Also computes delta[q] = sum_d dO[q][d] O[q][d] for its rows and publishes it for the dK/dV kernel.
+// =============================================================================================
+template <int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                              const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, const float* __restrict__ rcos,
+                                                              const float* __restrict__ rsin, uint16_t* __restrict__ dqkv, int T, int nh) {
+  constexpr int KT = 64;
+  constexpr int TILE = KT * 128;
+  constexpr int QB = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];  // [stage][K|V]
+
+  int tile_, h, b;
+  attn_block2<QB>(T, nh, tile_, h, b);
+  const int qt = (T + QB - 1) / QB - 1 - tile_;
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int q0 = qt * QB;
+  const int r0[2] = {q0 + 32 * wave, q0 + 32 * (7 - wave)};
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const float scale = 0.125f, c2 = scale * LOG2E;
+
+  bf16x8_t qf[2][4], dof[2][4];
+  float Lq[2], Dq[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    const bool qvalid = qrow < T;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      qf[qb][ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + d0) : zero_bf16x8();
+      dof[qb][ks] = qvalid ? ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + d0) : zero_bf16x8();
+    }
+    Lq[qb] = 0.f;
+    float part = 0.f;
+    if (qvalid) {
+      Lq[qb] = lse[((int64_t)b * nh + h) * T + qrow];  // base-2 LSE
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t o8 = ld_bf16x8(out + ((int64_t)b * T + qrow) * dm + h * HD + ks * 16 + hi * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += bf2f(o8[e]) * bf2f(dof[qb][ks][e]);
+      }
+    }
+    float d_lo, d_hi;
+    half_pair(part, d_lo, d_hi);  // rows beyond T hold zeros in both halves
+    Dq[qb] = d_lo + d_hi;
+    if (qvalid && hi == 0) delta[((int64_t)b * nh + h) * T + qrow] = Dq[qb];
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+    asm volatile("; q/dO fragments resident" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]), "v"(dof[qb][0]), "v"(dof[qb][1]),
+                 "v"(dof[qb][2]), "v"(dof[qb][3]), "v"(Lq[qb]), "v"(Dq[qb]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the delta stores too: nothing but LDS-DMA is counted from here on
+
+  f32x16_t dq[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    zero16(dq[qb][0]);
+    zero16(dq[qb][1]);
+  }
+
+  const int kv_hi = min(T, q0 + QB);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  constexpr int jt_lo = 0;
+  const int n = jt_hi;
+
+  TileDma dma;
+  dma.init(wave, lane, ld);
+  auto stage = [&](int slot, int jt) {  // 4 LDS-DMA instructions per wave
+    const int kv0 = jt * KT;
+    const uint16_t* src = base + (int64_t)kv0 * ld;
+    if (kv0 + KT <= T) {
+      dma.issue_full(smem + slot * 2 * TILE, src + dm, wave);
+      dma.issue_full(smem + slot * 2 * TILE + TILE, src + 2 * dm, wave);
+    } else {
+      dma.issue(smem + slot * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+      dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    }
+  };
+
+  // one 32-key block x one row block: S^T, dP^T, dS^T, dQ^T += K^T dS^T
+  auto block = [&](int qb_, int kb, const bf16x8_t (&kfr)[4], const bf16x8_t (&vfr)[4], const bf16x8_t (&ktr)[2][2], int kv0, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const int qb = qb_;
+    // key r of this lane is tile row kb*32 + (r&3) + 8*(r>>2) + 4*hi: visible iff  kb*32 + (r&3) + 8*(r>>2) <= c_hi
+    const int c_hi = r0[qb] + l31 - kv0 - 4 * hi;
+    f32x16_t s, dp;
+    zero16(s);
+    zero16(dp);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = mfma32(kfr[ks], qf[qb][ks], s);      // S^T[kv][q]
+      dp = mfma32(vfr[ks], dof[qb][ks], dp);   // dP^T[kv][q]
+    }
+    bf16x8_t dsf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = fast_exp2(__builtin_fmaf(s[r], c2, -Lq[qb]));
+      if (MASK) {
+        const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+        p = (c <= c_hi) ? p : 0.f;
+      }
+      dsf[r >> 3][r & 7] = f2bf(p * (dp[r] - Dq[qb]));  // x 1/sqrt(hd) once, in the epilogue
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dq[qb][db] = mfma32(ktr[db][s2], dsf[s2], dq[qb][db]);  // dQ^T[d][q]
+  };
+
+  auto compute = [&](int kv0, const char* sK, const char* sV, auto m0_tag, auto m1_tag) {
+    constexpr int M0 = decltype(m0_tag)::value, M1 = decltype(m1_tag)::value;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      __builtin_amdgcn_sched_barrier(0);  // 256 registers: one key block's fragments at a time
+      bf16x8_t kfr[4], vfr[4], ktr[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kfr[ks] = frag_rows(sK, kb * 32 + l31, ks, hi);
+        vfr[ks] = frag_rows(sV, kb * 32 + l31, ks, hi);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) ktr[db][s2] = frag_cols(sK, db, kb * 32 + s2 * 16 + 4 * hi, lane);
+      if (M0 == QB_UM) block(0, kb, kfr, vfr, ktr, kv0, std::false_type{});
+      if (M0 == QB_MASK) block(0, kb, kfr, vfr, ktr, kv0, std::true_type{});
+      if (M1 == QB_UM) block(1, kb, kfr, vfr, ktr, kv0, std::false_type{});
+      if (M1 == QB_MASK) block(1, kb, kfr, vfr, ktr, kv0, std::true_type{});
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < n) stage(i, jt_lo + i);
+  int i = 0, slot = 0;
+  auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
+    for (; jt_lo + i < jt_end; ++i) {
+      const int rem = min(NST - 2, n - 1 - i);
+      if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
+      else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+      else attn_wait_vm<0>();
+      attn_barrier();
+      if (i + NST - 1 < n) stage(slot == 0 ? NST - 1 : slot - 1, jt_lo + i + NST - 1);
+      if (active) compute((jt_lo + i) * KT, smem + slot * 2 * TILE, smem + slot * 2 * TILE + TILE, m0_tag, m1_tag);
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+    }
+  };
+  using OFF_ = std::integral_constant<int, QB_OFF>;
+  using UM_ = std::integral_constant<int, QB_UM>;
+  using MK_ = std::integral_constant<int, QB_MASK>;
+  const int a0 = min(jt_hi, r0[0] / KT), e0 = min(jt_hi, r0[0] / KT + 1);
+  const int a1 = min(jt_hi, r0[1] / KT), e1 = min(jt_hi, r0[1] / KT + 1);
+  run(a0, UM_{}, UM_{}, true);
+  run(e0, MK_{}, UM_{}, true);
+  run(a1, OFF_{}, UM_{}, true);
+  run(e1, OFF_{}, MK_{}, true);
+  run(jt_hi, OFF_{}, OFF_{}, false);
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    if (qrow < T) {
+      uint16_t* dqp = dqkv + ((int64_t)b * T + qrow) * ld + h * HD;
+      const int trow = qrow * 32;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = db * 32 + 8 * g + 4 * hi;
+          const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
+          const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
+          const float a0_ = dq[qb][db][4 * g + 0] * scale, b0 = dq[qb][db][4 * g + 1] * scale, a1_ = dq[qb][db][4 * g + 2] * scale,
+                      b1 = dq[qb][db][4 * g + 3] * scale;
+          bf16x4_t ov;  // inverse rotation: gradient w.r.t. the PRE-rotation q
+          ov[0] = f2bf(a0_ * c0 + b0 * s0);
+          ov[1] = f2bf(b0 * c0 - a0_ * s0);
+          ov[2] = f2bf(a1_ * c1 + b1 * s1);
+          ov[3] = f2bf(b1 * c1 - a1_ * s1);
+          st_bf16x4(dqp + d0, ov);
+        }
+    }
+  }
+}
+
+// =============================================================================================
+// backward dK / dV: 4 waves x 32 key rows (128-key tiles, K / V of a wave's rows in registers), Q | dO | statistics tiles of 64
+// queries through an NST-deep ring filled NST - 1 tiles ahead; every fragment of a 32-query block is requested before the block's first MFMA.
+// =============================================================================================
+template <int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                uint16_t* __restrict__ dqkv, int T, int nh) {
+  constexpr int QT = 64;
+  constexpr int TILE = QT * 128;          // 8 KiB
+  constexpr int STAGE = 2 * TILE + 512;   // Q | dO | statistics (lse[64], delta[64])
+  constexpr int KB = 128;
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+
+  int kt, h, b;  // key tile 0 meets every query tile: heaviest first
+  attn_block2<KB>(T, nh, kt, h, b);
+  const int dm = nh * HD, ld = 3 * dm;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int kv0 = kt * KB, kvw0 = kv0 + wave * 32;
+  const int kvrow = kvw0 + l31;
+  const bool kvalid = kvrow < T;
+  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
+  const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
+  const float* lrow = lse + ((int64_t)b * nh + h) * T;
+  const float* drow = delta + ((int64_t)b * nh + h) * T;
+  const float scale = 0.125f, c2 = scale * LOG2E;
+
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
+    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
+    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
+  }
+  const int nqt = (T + QT - 1) / QT;
+  const int jq_lo = kv0 / QT;
+  const int jq_hi = nqt;
+  const int n = jq_hi - jq_lo;
+  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
+               "v"(vf[3]));  // every ordinary load is consumed before the first DMA is in flight
+
+  f32x16_t dk[2], dv[2];
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+
+  TileDma dma, dmad;
+  dma.init(wave, lane, ld);
+  dmad.init(wave, lane, dm);
+  auto stage = [&](int slot, int jq) {  // 4 LDS-DMA instructions per wave, + 2 sixteen-lane ones on wave 0
+    const int qt0 = jq * QT;
+    char* dst = smem + slot * STAGE;
+    if (qt0 + QT <= T) {
+      dma.issue_full(dst, base + (int64_t)qt0 * ld, wave);
+      dmad.issue_full(dst + TILE, dobase + (int64_t)qt0 * dm, wave);
+    } else {
+      dma.issue(dst, base + (int64_t)qt0 * ld, ld, T - 1 - qt0, wave);
+      dma.issue(dst + TILE, dobase + (int64_t)qt0 * dm, dm, T - 1 - qt0, wave);
+    }
+    if (wave == 0 && lane < 16) {  // 64 floats = 16 lanes x 16 bytes per statistic (T % 4 == 0 is checked on the host)
+      const int q = min(qt0 + lane * 4, T - 4);
+      dma16_asm(lrow + q, dst + 2 * TILE);
+      dma16_asm(drow + q, dst + 2 * TILE + 256);
+    }
+  };
+
+  auto compute = [&](int qt0, const char* sQ, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const char* sDO = sQ + TILE;
+    const float* sL = reinterpret_cast<const float*>(sQ + 2 * TILE);
+    const float* sD = sL + 64;
+    // query r = 4g + e of this lane is tile row qb*32 + 8g + e + 4*hi: visible iff  c_lo <= qb*32 + 8g + e < c_end
+    const int c_lo = kvrow - qt0 - 4 * hi, c_end = T - qt0 - 4 * hi;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      __builtin_amdgcn_sched_barrier(0);  // one query block's fragments at a time
+      bf16x8_t qfr[4], dofr[4], dotr[2][2], qtr[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qfr[ks] = frag_rows(sQ, qb * 32 + l31, ks, hi);
+        dofr[ks] = frag_rows(sDO, qb * 32 + l31, ks, hi);
+      }
+      f32x4_t L4[4], D4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ql0 = qb * 32 + 8 * g + 4 * hi;
+        L4[g] = *reinterpret_cast<const f32x4_t*>(sL + ql0);  // base-2 LSE
+        D4[g] = *reinterpret_cast<const f32x4_t*>(sD + ql0);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dotr[db][s2] = frag_cols(sDO, db, qb * 32 + s2 * 16 + 4 * hi, lane);
+          qtr[db][s2] = frag_cols(sQ, db, qb * 32 + s2 * 16 + 4 * hi, lane);
+        }
+      f32x16_t s, dp;
+      zero16(s);
+      zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32(qfr[ks], kf[ks], s);       // S[q][kv]
+        dp = mfma32(dofr[ks], vf[ks], dp);    // dP[q][kv]
+      }
+      bf16x8_t pf[2], dsf[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float p = fast_exp2(__builtin_fmaf(s[r], c2, -L4[g][e]));
+          if (MASK) {
+            const int c = qb * 32 + 8 * g + e;
+            p = ((c >= c_lo) && (c < c_end)) ? p : 0.f;
+          }
+          const float dsv = p * (dp[r] - D4[g][e]);  // the 1/sqrt(hd) factor (a power of two: exact) is applied once, to dK, in the epilogue
+          pf[r >> 3][r & 7] = f2bf(p);
+          dsf[r >> 3][r & 7] = f2bf(dsv);
+        }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = mfma32(dotr[db][s2], pf[s2], dv[db]);   // dV^T[d][kv]
+          dk[db] = mfma32(qtr[db][s2], dsf[s2], dk[db]);   // dK^T[d][kv]
+        }
+    }
+  };
+
+  // per wave: tiles entirely above its first key (idle), the tiles its diagonal crosses (masked), the tiles below its last key (no mask),
+  // a partial last tile when T % 64 != 0 (masked)
+  const bool wave_rows = kvw0 < T;
+  const int jq_act = wave_rows ? min(jq_hi, max(jq_lo, kvw0 / QT)) : jq_hi;
+  const int jq_m = min(jq_hi, max(jq_act, (kvw0 + 31 + QT - 1) / QT));
+  const int jq_u = min(jq_hi, max(jq_m, T / QT));
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < n) stage(i, jq_lo + i);
+  int i = 0, slot = 0;
+  auto run = [&](int jq_end, auto mask_tag, bool active) {
+    for (; jq_lo + i < jq_end; ++i) {
+      // wait for this wave's pieces of tile i; the tiles issued after it (at most NST - 2) stay in flight: 4 instructions each, plus
+      // the statistics pieces on wave 0
+      const int rem = min(NST - 2, n - 1 - i);
+      constexpr int W0 = 6;
+      if (wave == 0) {
+        if (NST >= 4 && rem >= 2) attn_wait_vm<2 * W0>();
+        else if (NST >= 3 && rem == 1) attn_wait_vm<W0>();
+        else attn_wait_vm<0>();
+      } else {
+        if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
+        else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+        else attn_wait_vm<0>();
+      }
+      attn_barrier();
+      if (i + NST - 1 < n) stage(slot == 0 ? NST - 1 : slot - 1, jq_lo + i + NST - 1);
+      if (active) compute((jq_lo + i) * QT, smem + slot * STAGE, mask_tag);
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+    }
+  };
+  run(jq_act, std::true_type{}, false);
+  run(jq_m, std::true_type{}, true);
+  run(jq_u, std::false_type{}, true);
+  run(jq_hi, std::true_type{}, true);
+
+  if (kvalid) {
+    uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
+    uint16_t* dvp = dkp + dm;
+    const int trow = kvrow * 32;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        bf16x4_t ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
+        st_bf16x4(dvp + d0, ov);
+        const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
+        const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
+        const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
+        bf16x4_t ok;  // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
+        ok[0] = f2bf(a0 * c0 + b0 * s0);
+        ok[1] = f2bf(b0 * c0 - a0 * s0);
+        ok[2] = f2bf(a1 * c1 + b1 * s1);
+        ok[3] = f2bf(b1 * c1 - a1 * s1);
+        st_bf16x4(dkp + d0, ok);
+      }
+  }
+}
+
+// =============================================================================================
+// launchers (called from the C ABI entry points in attn.hip when no document mask is given)
+// =============================================================================================
+void plm_attn_fwd_causal(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
+  const dim3 grid((unsigned)(plm_cdiv(T, 256) * nh * B)), block(256);
+  hipLaunchKernelGGL((attn_fwd_causal_kernel<4>), grid, block, 0, s, qkv, out, lse, (int)T, (int)nh);
+}
+void plm_attn_bwd_causal(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
+                         const float* rs, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
+  const dim3 block(256);
+  // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
+  hipLaunchKernelGGL((attn_bwd_dq_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 256) * nh * B)), block, 0, s, qkv, out, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh);
+  hipLaunchKernelGGL((attn_bwd_dkdv_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), block, 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh);
+}

@@ -27,9 +27,6 @@ static void load_env() {
   g_env.tn_no_big = getenv("PLM_TN_NO_BIG") != nullptr;
   g_env.nt_no_hybrid = getenv("PLM_NT_NO_HYBRID") != nullptr;
   g_env.nt_hybrid_min_k = num("PLM_NT_HYBRID_MIN_K");
-  g_env.attn_fwd = (int)num("PLM_ATTN_FWD");
-  g_env.attn_dq = (int)num("PLM_ATTN_DQ");
-  g_env.attn_dkdv = (int)num("PLM_ATTN_DKDV");
 }
 const PlmEnv& plm_env() {
   static const bool once = (load_env(), true);

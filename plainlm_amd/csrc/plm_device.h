@@ -38,7 +38,6 @@ struct PlmEnv {
   bool tn_no_big;             // PLM_TN_NO_BIG: no persistent 256x256 TN kernel
   bool nt_no_hybrid;          // PLM_NT_NO_HYBRID: no whole-K + stream-K NT schedule
   long long nt_hybrid_min_k;  // PLM_NT_HYBRID_MIN_K: lowers the hybrid schedule's thresholds (-1: defaults)
-  int attn_fwd, attn_dq, attn_dkdv;  // PLM_ATTN_FWD / _DQ / _DKDV: attention kernel variants (A/B runs; -1: defaults)
 };
 const PlmEnv& plm_env();
 
