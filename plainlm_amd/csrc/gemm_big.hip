@@ -25,6 +25,8 @@
 
 #include "plm_device.h"
 
+#include <initializer_list>
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
@@ -1186,6 +1188,15 @@ extern "C" size_t plm_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return (size_t)p.nslabs * (size_t)(M - (int64_t)p.rfull * 256) * (size_t)N * sizeof(float);
 }
 
+// 16-byte alignment of every pointer a fused launch touches with 16-byte vector accesses (LDS-DMA sources, row stores, the saved fc1 output,
+// the RoPE tables): a caller of the C ABI with a misaligned view gets the two-launch fallback (whose GEMM checks its own operands), not a
+// misaligned global_load_lds_dwordx4
+static bool aligned16(std::initializer_list<const void*> ptrs) {
+  uintptr_t v = 0;
+  for (const void* p : ptrs) v |= reinterpret_cast<uintptr_t>(p);
+  return (v & 15) == 0;
+}
+
 // fc1 + SwiGLU in one launch (see GLU above).  Returns false when the shape does not qualify (the caller then runs the GEMM and
 // plm_swiglu_fwd separately - same bits).
 bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, uint16_t* act,
@@ -1197,6 +1208,7 @@ bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, i
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if (K % 64 != 0 || N % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldact % 8 != 0) return false;
+  if (!aligned16({A, B, C, act})) return false;
   const int tm = (int)plm_cdiv(M, 256), tn = (int)(N / 256);
   const int slots = persistent_slots();
   const int nt_ = tm * tn;
@@ -1216,6 +1228,7 @@ bool plm_launch_gemm_nt_glub(const uint16_t* A, int64_t lda, const uint16_t* B, 
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if (K % 64 != 0 || h % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldu % 4 != 0 || lddu % 8 != 0) return false;
+  if (!aligned16({A, B, DU}) || (reinterpret_cast<uintptr_t>(U) & 7) != 0) return false;  // U is read in 8-byte pieces
   const int tm = (int)plm_cdiv(M, 256), tn = (int)(h / 256);
   const int slots = persistent_slots();
   const int nt_ = tm * tn;
@@ -1235,6 +1248,7 @@ bool plm_launch_gemm_nt_rope(const uint16_t* A, int64_t lda, const uint16_t* B, 
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if (K % 64 != 0 || N % 8 != 0 || M < 512 || N < 128 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
+  if (!aligned16({A, B, C, rcos, rsin})) return false;
   const int tm = (int)plm_cdiv(M, 256);
   const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
   const int slots = persistent_slots();

@@ -27,10 +27,13 @@ from . import _lib
 # finish(), so the forward pass and the lm_head backward (no collective in flight) keep all 256 CUs (the reserve costs
 # 5.5 % on the GEMMs it applies to, run 30).
 COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
-# The cap is PER COMMUNICATOR (ncclConfig_t.maxCTAs through plm_comm_init_capped), not the process-wide NCCL_MAX_NCHANNELS:
-# the buckets that are reduced while backward runs use the capped communicator, the tail (embed_tokens: ready when backward
-# has ended, nothing left to overlap with) uses an uncapped one split off it, so the exposed 154 MB all-reduce runs on every
-# channel / xGMI link RCCL wants.  Only the torch.distributed fallback still needs the environment variable.
+# The cap is set twice for world > 1: PER COMMUNICATOR (ncclConfig_t.maxCTAs through plm_comm_init_capped) and, before the first
+# RCCL call of the process, as NCCL_MAX_NCHANNELS (unless the caller has set it) - the per-communicator form has only ever run with ONE
+# rank (tests/test_model_gpu.py::test_rccl_capped_communicator_and_split_tail_single_rank), and the environment variable is also
+# the only knob of the torch.distributed fallback.  PLM_COMM_TAIL=1 (opt-in until a multi-GPU run has been recorded) adds an
+# UNCAPPED communicator split off the capped one for the tail bucket (embed_tokens: ready when backward has ended, nothing
+# left to overlap with), so that the exposed 154 MB all-reduce may use every channel - it needs NCCL_MAX_NCHANNELS left unset by us,
+# which PLM_COMM_TAIL=1 therefore does.
 
 
 class RcclComm:
@@ -267,6 +270,8 @@ def make_comm(device, backend=None, group=None):
       return RcclComm(rank, world, idx, store_group=group)
     # The direct communicator is created collectively; if it fails on ANY rank every rank falls back to torch.distributed's
     # nccl (= RCCL) backend, so that a box whose RCCL set-up differs from the build machine still trains.
+    if os.environ.get('PLM_COMM_TAIL', '0') != '1':
+      os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))  # before ANY RCCL call: RCCL may read it once
     comm, err = None, None
     try:
       comm = RcclComm(rank, world, idx, store_group=group)
@@ -276,8 +281,8 @@ def make_comm(device, backend=None, group=None):
       return comm
     if comm is not None:
       comm.close()
-    print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl', flush=True)
-    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))  # process-wide cap: the only knob torch's backend offers
+    print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl '
+          f'(NCCL_MAX_NCHANNELS={os.environ.get("NCCL_MAX_NCHANNELS")})', flush=True)
     return TorchDistComm(dist.new_group(backend='nccl'))
   if not dist.is_initialized():
     raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")
@@ -286,9 +291,9 @@ def make_comm(device, backend=None, group=None):
 
 def make_tail_comm(comm, group=None):
   """Uncapped communicator for the buckets that are reduced after backward has ended (see COMM_CUS), split off the capped
-  one; None when the data plane is not direct RCCL, the capped one is not capped, PLM_COMM_TAIL=0, or the split fails on
+  one; None when the data plane is not direct RCCL, the capped one is not capped, PLM_COMM_TAIL is not 1 (opt-in), or the split fails on
   any rank (every rank then keeps using `comm` alone - agreed collectively)."""
-  if not isinstance(comm, RcclComm) or comm.max_ctas <= 0 or os.environ.get('PLM_COMM_TAIL', '1') == '0':
+  if not isinstance(comm, RcclComm) or comm.max_ctas <= 0 or os.environ.get('PLM_COMM_TAIL', '0') != '1':
     return None
   tail, err = None, None
   try:

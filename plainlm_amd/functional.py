@@ -31,6 +31,12 @@ class GradSink:
     # exist: with a gradient consumer attached (DDP buckets, `on_ready`) a group is three transformer blocks (85 MB of
     # gradients, about one 64 MiB bucket and a half), without one it is the whole model (flushed by the embedding's backward).
     self.dw_group_local, self.dw_group_ddp = 48, 12
+    # The queue keeps each Linear's dy and saved input alive until its launch (autograd would free them node by node): ~0.8 GB per
+    # block at 160M / 32 x 1024 tokens, ~10 GB for the whole model.  Bounded by bytes as well as by count: the group is issued
+    # early once it pins more than this (PLM_DW_QUEUE_GB; default a quarter of the device's memory, never reached by the BASELINE
+    # configs), so deeper models and larger micro-batches do not run out of memory where a group of four blocks would not.
+    self.dw_queue_bytes_max = None
+    self.dw_queue_bytes = 0
     self.dw_queue = []
     # RMSNorm weight gradients: the backward kernel leaves per-block partial sums; their column sums (25 launch-bound
     # kernels at the 160M size) are queued and run as ONE launch when backward reaches the embedding (flush_dw)
@@ -43,7 +49,13 @@ class GradSink:
   def defer_dw(self, dy, x, p):
     """Queue dW(p) (+)= dy^T x; runs when the group is full or at flush_dw()."""
     self.dw_queue.append((dy, x, p, not self.first_write(p)))
-    if len(self.dw_queue) >= (self.dw_group_ddp if self.on_ready is not None else self.dw_group_local):
+    self.dw_queue_bytes += dy.numel() * dy.element_size() + x.numel() * x.element_size()
+    if self.dw_queue_bytes_max is None:
+      import os
+      gb = os.environ.get('PLM_DW_QUEUE_GB')
+      self.dw_queue_bytes_max = int(float(gb) * 2 ** 30) if gb else torch.cuda.get_device_properties(dy.device).total_memory // 4
+    if (len(self.dw_queue) >= (self.dw_group_ddp if self.on_ready is not None else self.dw_group_local)
+        or self.dw_queue_bytes > self.dw_queue_bytes_max):
       self._flush_linear_dw()
 
   def defer_norm_dw(self, part, p):
@@ -68,6 +80,7 @@ class GradSink:
 
   def _flush_linear_dw(self):
     q, self.dw_queue = self.dw_queue, []
+    self.dw_queue_bytes = 0
     if not q:
       return
     if len(q) == 1 or not ops.gemm_tn_grouped([(dy, x, p.main_grad, acc, None) for dy, x, p, acc in q]):
@@ -219,19 +232,26 @@ def _norm_dw(norm, dy, x, w, rstd, gin, want_bf16):
 
 
 class NormFn(torch.autograd.Function):
-  """y = bf16(RMSNorm(x) * w) for an fp32 x that is not modified (first block)."""
+  """(x, y) = (x, bf16(RMSNorm(x) * w)) for the fp32 x of the first block (the embedding output), which feeds the norm AND the residual
+  stream.  x is handed back as a second output (an alias, no copy) so that both of its consumers' gradients arrive HERE: the residual
+  path's gradient goes into the norm-backward kernel as its `gin` term - autograd would otherwise sum the two [M, d] fp32 gradients
+  with an elementwise add of its own (the one non-plm kernel round 2's step trace still showed)."""
 
   @staticmethod
   def forward(ctx, x, weight, norm):
     _, y, rstd = ops.rmsnorm_fwd(x, weight, norm.eps)
     ctx.save_for_backward(x, weight, rstd)
     ctx.norm = norm
-    return y
+    ctx.set_materialize_grads(False)
+    return x.view_as(x), y
 
   @staticmethod
-  def backward(ctx, dy):
+  def backward(ctx, g_x, g_y):
     x, w, rstd = ctx.saved_tensors
-    dx, _, dw = _norm_dw(ctx.norm, dy.contiguous(), x, w, rstd, None, False)
+    if g_y is None:
+      return g_x, None, None
+    gin = g_x.contiguous() if g_x is not None else None
+    dx, _, dw = _norm_dw(ctx.norm, g_y.contiguous(), x, w, rstd, gin, False)
     return dx, dw, None
 
 

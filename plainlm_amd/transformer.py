@@ -122,7 +122,7 @@ class RMSNorm(nn.Module):
 
   def forward(self, x):
     lead = x.shape
-    y = Fn.NormFn.apply(x.reshape(-1, lead[-1]).contiguous(), self.weight, self)
+    _, y = Fn.NormFn.apply(x.reshape(-1, lead[-1]).contiguous(), self.weight, self)
     return y.view(lead)
 
 
@@ -177,7 +177,7 @@ class Block(nn.Module):
     """x fp32 [M,d] residual stream, branch bf16 [M,d] = previous block's MLP output (or None).
     Returns (x_mid, mlp_out): the residual add of the MLP output is fused into the NEXT norm."""
     if branch is None:
-      n1 = Fn.NormFn.apply(x, self.attn_norm.weight, self.attn_norm)
+      x, n1 = Fn.NormFn.apply(x, self.attn_norm.weight, self.attn_norm)
     else:
       x, n1 = Fn.AddNormFn.apply(x, branch, self.attn_norm.weight, self.attn_norm)
     a = self.attn(n1, rope, doc_start, B, T)

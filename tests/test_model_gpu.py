@@ -564,8 +564,8 @@ def test_rccl_reducer_single_rank(P, mdl):
 
 
 @pytest.mark.timeout(300, method='thread')  # a hung ncclCommSplit must end the run, not the box
-def test_rccl_capped_communicator_and_split_tail_single_rank(P, mdl):
-  """The communicator pair multi-GPU runs use by default (plainlm_amd/ddp.py::make_comm / make_tail_comm), on one GPU:
+def test_rccl_capped_communicator_and_split_tail_single_rank(P, mdl, monkeypatch):
+  """The communicator pair multi-GPU runs use under PLM_COMM_TAIL=1 (plainlm_amd/ddp.py::make_comm / make_tail_comm), on one GPU:
   plm_comm_init_capped with maxCTAs = 16 (ncclCommInitRankConfig), plm_comm_split for the uncapped tail communicator
   (ncclCommSplit), GradReducer routing the last bucket (embed_tokens + norm weights) through the child.  One rank: the mean
   is the identity, so the flat gradient must be bit-equal to the un-reduced one, and the tail bucket must have gone
@@ -580,6 +580,8 @@ def test_rccl_capped_communicator_and_split_tail_single_rank(P, mdl):
   want = m._flat_grad.clone()
   comm = ddp.RcclComm(0, 1, torch.cuda.current_device(), max_ctas=16)
   assert comm.max_ctas == 16
+  assert ddp.make_tail_comm(comm) is None  # opt-in until a multi-GPU run has been recorded
+  monkeypatch.setenv('PLM_COMM_TAIL', '1')
   tail = ddp.make_tail_comm(comm)
   assert isinstance(tail, ddp.RcclComm) and tail.max_ctas == 0 and tail.handle.value != comm.handle.value
   red = ddp.GradReducer(m._flat_grad, list(m.parameters()), m._grad_spans, comm, bucket_cap_mb=0.25, force=True, reserve_cus=16,
