@@ -49,13 +49,15 @@ class GradSink:
   def defer_dw(self, dy, x, p):
     """Queue dW(p) (+)= dy^T x; runs when the group is full or at flush_dw()."""
     self.dw_queue.append((dy, x, p, not self.first_write(p)))
-    self.dw_queue_bytes += dy.numel() * dy.element_size() + x.numel() * x.element_size()
-    if self.dw_queue_bytes_max is None:
-      import os
-      gb = os.environ.get('PLM_DW_QUEUE_GB')
-      self.dw_queue_bytes_max = int(float(gb) * 2 ** 30) if gb else torch.cuda.get_device_properties(dy.device).total_memory // 4
+    if isinstance(dy, torch.Tensor) and isinstance(x, torch.Tensor):
+      self.dw_queue_bytes += dy.numel() * dy.element_size() + x.numel() * x.element_size()
+      if self.dw_queue_bytes_max is None:
+        import os
+        gb = os.environ.get('PLM_DW_QUEUE_GB')
+        self.dw_queue_bytes_max = (int(float(gb) * 2 ** 30) if gb else
+                                   torch.cuda.get_device_properties(dy.device).total_memory // 4 if dy.is_cuda else 1 << 62)
     if (len(self.dw_queue) >= (self.dw_group_ddp if self.on_ready is not None else self.dw_group_local)
-        or self.dw_queue_bytes > self.dw_queue_bytes_max):
+        or (self.dw_queue_bytes_max is not None and self.dw_queue_bytes > self.dw_queue_bytes_max)):
       self._flush_linear_dw()
 
   def defer_norm_dw(self, part, p):

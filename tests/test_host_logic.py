@@ -242,3 +242,15 @@ def test_gradsink_groups_weight_gradient_gemms(monkeypatch):
     sink.defer_dw('dy', 'x', params[0])                             # second micro-step of the window: accumulate
     sink.flush_dw()
     assert calls == [('single', True)]
+  # the queue is bounded by the bytes it keeps alive as well: 5 pairs of 2 x 400 bytes against a 3000-byte budget
+  import torch
+  sink = Fn.GradSink()
+  sink.dw_queue_bytes_max = 3000
+  calls.clear()
+  params = [FakeParam() for _ in range(5)]
+  sink.begin_window()
+  for p in params:
+    sink.defer_dw(torch.zeros(100), torch.zeros(100), p)
+  assert [len(c) for c in calls] == [4] and sink.dw_queue_bytes == 800  # issued when the 4th pair crossed the budget; one pair left
+  sink.flush_dw()
+  assert calls[1] == ('single', False) and sink.dw_queue_bytes == 0
