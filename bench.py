@@ -132,12 +132,12 @@ def csrc_sha():
   return h.hexdigest()[:16]
 
 
-PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_pmc_gemm_traffic.json')
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_pmc_gemm_traffic.json')
 
 
 def pmc_traffic(family, config, tokens, n_layers):
   """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
-  (profiles/r02_pmc_gemm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM shape of the
+  (profiles/r03_pmc_gemm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM shape of the
   160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the profiler on
   itself, so the figure is the profile's, averaged over the launches of one step - and ONLY when the profile was taken on
   this very tree (the profile records the sha of plainlm_amd/csrc): otherwise traffic stays null and the reason is stated."""

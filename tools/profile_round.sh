@@ -1,8 +1,8 @@
 #!/bin/bash
-# Evidence run of a round on one MI355X box:  gpurun -- 'bash tools/profile_round.sh r02'
+# Evidence run of a round on one MI355X box:  gpurun -- 'bash tools/profile_round.sh r03'
 # kernel trace of bench.py, PMC passes (HBM-side traffic, MFMA utilisation, issue / stall counters) over every MFMA kernel of the
 # step, per-kernel micro-benchmarks, the bench line itself.  Summaries land in gpurun_out/<tag>/ ; copy what is judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$(dirname "$0")/.."
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -11,6 +11,10 @@ R=$PWD
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python tools/kbench.py --iters 20 --json $O/kbench.jsonl > $O/kbench.log 2>&1; echo "kbench rc=$?"
 python tools/engine_bench.py > $O/engine_bench.txt 2>&1; echo "engine_bench rc=$?"
+python bench.py --config 420m --no-extras > $O/bench_420m.json 2> $O/bench_420m.err; echo "bench 420m rc=$?"
+python bench.py --doc-mask --no-extras > $O/bench_docmask.json 2> $O/bench_docmask.err; echo "bench doc-mask rc=$?"
+python bench.py --doc-mask --micro-batch 8 --no-extras > $O/bench_docmask_b8.json 2> $O/bench_docmask_b8.err; echo "bench doc-mask B=8 rc=$?"
+PLM_FORCE_REDUCER=1 python bench.py --no-extras > $O/bench_force_reducer.json 2> $O/bench_force_reducer.err; echo "bench 1-GPU reducer what-if rc=$?"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-extras > $R/$O/trace.log 2>&1; echo "trace rc=$?"
 python3 $R/tools/prof_kernels.py > $R/$O/order.log 2>&1; echo "order rc=$?"
