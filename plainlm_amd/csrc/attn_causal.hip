@@ -34,6 +34,28 @@ __device__ __forceinline__ void attn_block2(int T, int nh, int& tile, int& h, in
   b = bh / nh;
 }
 
+// A wave's 32-row x 64-column bf16 block leaves as whole 128-byte rows: lane (l31, hi) holds row l31 in 8-byte pieces (head dims
+// db*32 + 8g + 4hi .. + 3 = piece `hi` of the 16-byte chunk c16 = 4 db + g); the pieces go through a 4 KiB LDS region of the wave's own
+// (chunk c16 of row r at position c16 ^ (r & 7): spreads a column of chunks over the banks) and come back as 16 bytes per lane, 8 lanes
+// per row - 4 store instructions of 8 full lines each instead of 16 that touch 32 lines each (the per-block cost the timing-only builds
+// showed: launch + Q loads + O stores alone were 30 of the forward kernel's 88 us).
+struct RowStage {
+  char* base;  // 4 KiB, private to the wave, not read by anyone else any more
+  int lane;
+  __device__ __forceinline__ void put(int l31, int hi, int c16, bf16x4_t v) const {
+    *reinterpret_cast<bf16x4_t*>(base + l31 * 128 + ((c16 ^ (l31 & 7)) << 4) + hi * 8) = v;
+  }
+  // rows row0 .. row0 + 31 of a [*, ld] bf16 matrix at column col0; rows >= row_end are not stored
+  __device__ __forceinline__ void flush(uint16_t* dst, int64_t ld, int row0, int row_end, int col0) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3), c16 = lane & 7;
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(base + row * 128 + ((c16 ^ (row & 7)) << 4));
+      if (row0 + row < row_end) st_bf16x8(dst + (int64_t)(row0 + row) * ld + col0 + c16 * 8, v);
+    }
+  }
+};
+
 #define ATTN_DEFER_LOG2 8.0f  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
 
 enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };  // a 32-row block on a key tile: above its diagonal / no mask needed / masked
@@ -219,26 +241,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t*
   run(e1, OFF_{}, MK_{}, true);
   run(jt_hi, OFF_{}, OFF_{}, false);
 
+  // every wave has passed the last tile's barrier: all slots but the last tile's are free; slot n % NST holds this workgroup's O staging
+  const RowStage rs{smem + (n % NST) * 2 * TILE + wave * 4096, lane};
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = r0[qb] + l31;
     float l_lo, l_hi;
     half_pair(lsum[qb], l_lo, l_hi);
     const float ltot = l_lo + l_hi;
-    if (qrow < T) {
-      const float inv = 1.f / ltot;
-      uint16_t* op = out + ((int64_t)b * T + qrow) * dm + h * HD;
+    const float inv = 1.f / ltot;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4_t v;
+      for (int g = 0; g < 4; ++g) {
+        bf16x4_t v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[qb][db][4 * g + e] * inv);
-          st_bf16x4(op + db * 32 + 8 * g + 4 * hi, v);
-        }
-      if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = mc[qb] + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
-    }
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[qb][db][4 * g + e] * inv);
+        rs.put(l31, hi, db * 4 + g, v);
+      }
+    if (qrow < T && hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = mc[qb] + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
+    rs.flush(out + (int64_t)b * T * dm, dm, r0[qb], T, h * HD);
   }
 }
 
@@ -407,29 +429,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
   run(e1, OFF_{}, MK_{}, true);
   run(jt_hi, OFF_{}, OFF_{}, false);
 
+  const RowStage rs{smem + (n % NST) * 2 * TILE + wave * 4096, lane};  // a slot nobody reads any more (see the forward kernel)
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = r0[qb] + l31;
-    if (qrow < T) {
-      uint16_t* dqp = dqkv + ((int64_t)b * T + qrow) * ld + h * HD;
-      const int trow = qrow * 32;
+    const int trow = min(r0[qb] + l31, T - 1) * 32;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d0 = db * 32 + 8 * g + 4 * hi;
-          const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
-          const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
-          const float a0_ = dq[qb][db][4 * g + 0] * scale, b0 = dq[qb][db][4 * g + 1] * scale, a1_ = dq[qb][db][4 * g + 2] * scale,
-                      b1 = dq[qb][db][4 * g + 3] * scale;
-          bf16x4_t ov;  // inverse rotation: gradient w.r.t. the PRE-rotation q
-          ov[0] = f2bf(a0_ * c0 + b0 * s0);
-          ov[1] = f2bf(b0 * c0 - a0_ * s0);
-          ov[2] = f2bf(a1_ * c1 + b1 * s1);
-          ov[3] = f2bf(b1 * c1 - a1_ * s1);
-          st_bf16x4(dqp + d0, ov);
-        }
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
+        const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
+        const float a0_ = dq[qb][db][4 * g + 0] * scale, b0 = dq[qb][db][4 * g + 1] * scale, a1_ = dq[qb][db][4 * g + 2] * scale,
+                    b1 = dq[qb][db][4 * g + 3] * scale;
+        bf16x4_t ov;  // inverse rotation: gradient w.r.t. the PRE-rotation q
+        ov[0] = f2bf(a0_ * c0 + b0 * s0);
+        ov[1] = f2bf(b0 * c0 - a0_ * s0);
+        ov[2] = f2bf(a1_ * c1 + b1 * s1);
+        ov[3] = f2bf(b1 * c1 - a1_ * s1);
+        rs.put(l31, hi, db * 4 + g, ov);
+      }
+    rs.flush(dqkv + (int64_t)b * T * ld, ld, r0[qb], T, h * HD);
   }
 }
 
@@ -599,30 +619,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
   run(jq_u, std::false_type{}, true);
   run(jq_hi, std::true_type{}, true);
 
-  if (kvalid) {
-    uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
-    uint16_t* dvp = dkp + dm;
-    const int trow = kvrow * 32;
+  const RowStage rs{smem + (n % NST) * STAGE + wave * 4096, lane};  // a slot nobody reads any more (see the forward kernel)
+  const int trow = min(kvrow, T - 1) * 32;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        bf16x4_t ov;
+    for (int g = 0; g < 4; ++g) {
+      bf16x4_t ov;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
-        st_bf16x4(dvp + d0, ov);
-        const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
-        const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
-        const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
-        bf16x4_t ok;  // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
-        ok[0] = f2bf(a0 * c0 + b0 * s0);
-        ok[1] = f2bf(b0 * c0 - a0 * s0);
-        ok[2] = f2bf(a1 * c1 + b1 * s1);
-        ok[3] = f2bf(b1 * c1 - a1 * s1);
-        st_bf16x4(dkp + d0, ok);
-      }
-  }
+      for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
+      rs.put(l31, hi, db * 4 + g, ov);
+    }
+  rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, 2 * dm + h * HD);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = db * 32 + 8 * g + 4 * hi;
+      const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
+      const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
+      const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
+      bf16x4_t ok;  // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
+      ok[0] = f2bf(a0 * c0 + b0 * s0);
+      ok[1] = f2bf(b0 * c0 - a0 * s0);
+      ok[2] = f2bf(a1 * c1 + b1 * s1);
+      ok[3] = f2bf(b1 * c1 - a1 * s1);
+      rs.put(l31, hi, db * 4 + g, ok);
+    }
+  rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, dm + h * HD);
 }
 
 // =============================================================================================
