@@ -190,21 +190,20 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_doc_kernel(const uint16_t* __
   float l_lo, l_hi;
   half_pair(lsum, l_lo, l_hi);
   const float ltot = l_lo + l_hi;
-  if (qvalid) {
-    const float inv = 1.f / ltot;
-    uint16_t* op = out + ((int64_t)b * T + qrow) * dm + h * HD;
+  const float inv = 1.f / ltot;
+  const RowStage rs{smem + wave * 4096, lane};  // every wave is past the last tile's barrier: the stages are free (see attn_common.h)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+  for (int db = 0; db < 2; ++db) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4_t v;
+    for (int g = 0; g < 4; ++g) {
+      bf16x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[db][4 * g + e] * inv);
-        st_bf16x4(op + db * 32 + 8 * g + 4 * hi, v);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = f2bf(o[db][4 * g + e] * inv);
+      rs.put(l31, hi, db * 4 + g, v);
     }
-    if (hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = m * c2 + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
   }
+  if (qvalid && hi == 0) lse[((int64_t)b * nh + h) * T + qrow] = m * c2 + __builtin_amdgcn_logf(ltot);  // base-2 LSE: the backward's exp2 argument directly
+  rs.flush(out + (int64_t)b * T * dm, dm, qw0, T, h * HD);
 }
 
 // =============================================================================================
@@ -348,31 +347,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_doc_kernel(const uint16_
   int st = 0;
   for (int jq = jq_lo; jq < jq_hi; ++jq, st ^= 1) tile_body(jq, st);
 
-  if (kvalid) {
-    uint16_t* dkp = dqkv + ((int64_t)b * T + kvrow) * ld + dm + h * HD;
-    uint16_t* dvp = dkp + dm;
+  const RowStage rs{smem + wave * 4096, lane};  // every wave is past the last tile's barrier: the stages are free
+  const int trow = min(kvrow, T - 1) * 32;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+  for (int db = 0; db < 2; ++db) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        bf16x4_t ov;
+    for (int g = 0; g < 4; ++g) {
+      bf16x4_t ov;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
-        st_bf16x4(dvp + d0, ov);
-        // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
-        const float c0 = rcos[kvrow * 32 + d0 / 2], c1 = rcos[kvrow * 32 + d0 / 2 + 1];
-        const float s0 = rsin[kvrow * 32 + d0 / 2], s1 = rsin[kvrow * 32 + d0 / 2 + 1];
-        const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
-        bf16x4_t ok;
-        ok[0] = f2bf(a0 * c0 + b0 * s0);
-        ok[1] = f2bf(b0 * c0 - a0 * s0);
-        ok[2] = f2bf(a1 * c1 + b1 * s1);
-        ok[3] = f2bf(b1 * c1 - a1 * s1);
-        st_bf16x4(dkp + d0, ok);
-      }
+      for (int e = 0; e < 4; ++e) ov[e] = f2bf(dv[db][4 * g + e]);
+      rs.put(l31, hi, db * 4 + g, ov);
     }
   }
+  rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, 2 * dm + h * HD);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = db * 32 + 8 * g + 4 * hi;
+      // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
+      const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
+      const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
+      const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
+      bf16x4_t ok;
+      ok[0] = f2bf(a0 * c0 + b0 * s0);
+      ok[1] = f2bf(b0 * c0 - a0 * s0);
+      ok[2] = f2bf(a1 * c1 + b1 * s1);
+      ok[3] = f2bf(b1 * c1 - a1 * s1);
+      rs.put(l31, hi, db * 4 + g, ok);
+    }
+  }
+  rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, dm + h * HD);
 }
 
 // =============================================================================================
@@ -496,25 +501,25 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_doc_kernel(const uint16_t*
   int st = 0;
   for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st);
 
-  if (qvalid) {
-    uint16_t* dqp = dqkv + ((int64_t)b * T + qrow) * ld + h * HD;
+  const RowStage rs{smem + wave * 4096, lane};  // every wave is past the last tile's barrier: the stages are free
+  const int trow = min(qrow, T - 1) * 32;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+  for (int db = 0; db < 2; ++db) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        const float c0 = rcos[qrow * 32 + d0 / 2], c1 = rcos[qrow * 32 + d0 / 2 + 1];
-        const float s0 = rsin[qrow * 32 + d0 / 2], s1 = rsin[qrow * 32 + d0 / 2 + 1];
-        const float a0 = dq[db][4 * g + 0] * scale, b0 = dq[db][4 * g + 1] * scale, a1 = dq[db][4 * g + 2] * scale, b1 = dq[db][4 * g + 3] * scale;
-        bf16x4_t ov;
-        ov[0] = f2bf(a0 * c0 + b0 * s0);
-        ov[1] = f2bf(b0 * c0 - a0 * s0);
-        ov[2] = f2bf(a1 * c1 + b1 * s1);
-        ov[3] = f2bf(b1 * c1 - a1 * s1);
-        st_bf16x4(dqp + d0, ov);
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = db * 32 + 8 * g + 4 * hi;
+      const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
+      const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
+      const float a0 = dq[db][4 * g + 0] * scale, b0 = dq[db][4 * g + 1] * scale, a1 = dq[db][4 * g + 2] * scale, b1 = dq[db][4 * g + 3] * scale;
+      bf16x4_t ov;
+      ov[0] = f2bf(a0 * c0 + b0 * s0);
+      ov[1] = f2bf(b0 * c0 - a0 * s0);
+      ov[2] = f2bf(a1 * c1 + b1 * s1);
+      ov[3] = f2bf(b1 * c1 - a1 * s1);
+      rs.put(l31, hi, db * 4 + g, ov);
     }
   }
+  rs.flush(dqkv + (int64_t)b * T * ld, ld, qw0, T, h * HD);
 }
 
 // =============================================================================================

@@ -82,3 +82,25 @@ __device__ __forceinline__ void zero16(f32x16_t& v) {
   for (int r = 0; r < 16; ++r) v[r] = 0.f;
 }
 
+// A wave's 32-row x 64-column bf16 block leaves as whole 128-byte rows: lane (l31, hi) holds row l31 in 8-byte pieces (head dims
+// db*32 + 8g + 4hi .. + 3 = piece `hi` of the 16-byte chunk c16 = 4 db + g); the pieces go through a 4 KiB LDS region of the wave's own
+// (chunk c16 of row r at position c16 ^ (r & 7): spreads a column of chunks over the banks) and come back as 16 bytes per lane, 8 lanes
+// per row - 4 store instructions of 8 full lines each instead of 16 that touch 32 lines each (the per-block cost the timing-only builds
+// showed: launch + Q loads + O stores alone were 30 of the forward kernel's 88 us).
+struct RowStage {
+  char* base;  // 4 KiB, private to the wave, not read by anyone else any more
+  int lane;
+  __device__ __forceinline__ void put(int l31, int hi, int c16, bf16x4_t v) const {
+    *reinterpret_cast<bf16x4_t*>(base + l31 * 128 + ((c16 ^ (l31 & 7)) << 4) + hi * 8) = v;
+  }
+  // rows row0 .. row0 + 31 of a [*, ld] bf16 matrix at column col0; rows >= row_end are not stored
+  __device__ __forceinline__ void flush(uint16_t* dst, int64_t ld, int row0, int row_end, int col0) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3), c16 = lane & 7;
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(base + row * 128 + ((c16 ^ (row & 7)) << 4));
+      if (row0 + row < row_end) st_bf16x8(dst + (int64_t)(row0 + row) * ld + col0 + c16 * 8, v);
+    }
+  }
+};
+
