@@ -15,7 +15,10 @@
 //   * The forward softmax defers the running-max update (the O rescale) until a row's maximum has grown by more than 2^8: with the exact
 //     maximum SOME row of a wave grows in almost every tile, so the "skip when nothing moved" test of generation one never skipped.
 //   * Mask code (diagonal tiles only) lives in separate per-wave loops; masks are two integer thresholds per lane and tile.
-// Measured (B = 32, T = 1024, 12 heads): forward 95 -> 88 us, dQ 139 -> 131 us, dK/dV 175 -> 167 us.  What did NOT work is recorded in
+//   * Output blocks (O, dQ, dK, dV) leave as whole 128-byte rows through a wave-private LDS transposition (RowStage, attn_common.h) instead
+//     of 8-byte row-per-lane stores that touched 32 cache lines per instruction: backward 300 -> 273 us per layer - more than everything
+//     above together.
+// Measured (B = 32, T = 1024, 12 heads, same-box A/Bs): forward 95 -> 86 us, backward (dQ + dK/dV) 314 -> 273 us per layer.  What did NOT work is recorded in
 // DESIGN.md section 5.3 (a persistent forward with one Q/K/V ring and a dynamic item queue; 64 key rows per wave at one wave per SIMD).
 #include "plm_device.h"
 
