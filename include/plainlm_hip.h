@@ -151,6 +151,9 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  * query i attends key j iff doc_start[i] <= j <= i (doc_start non-decreasing in i).
  * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (fp32 math, bf16 result).  The training step does not launch it: the
  *               rotation is fused into plm_qkv_rope_bf16's GEMM epilogue; this is that entry point's fallback and the tests' yardstick.
+ * Two kernel families behind the same two entry points: doc_start == NULL (plain causal batches) takes the 256-query-tile kernels of
+ * csrc/attn_causal.hip, a document mask the 128-row-tile kernels of csrc/attn.hip; lse / delta are only meaningful within one
+ * forward / backward pair of the same family (pass the same doc_start to both).
  * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (BASE-2 log-sum-exp of the
  *               scaled scores, = LSE / ln 2: the form plm_attn_bwd's exp2 consumes; opaque to the caller otherwise).  No transposed / contiguous copies of q, k, v are made anywhere.
  * plm_attn_bwd: same rotated qkv; dqkv bf16[B*T, 3*nh*hd] = gradient w.r.t. the PRE-rotation q, k (the inverse
