@@ -1,0 +1,242 @@
+"""Parity at the sizes bench.py times (BASELINE configs[1]: 160M, batch 32 x seq 1024 -> M = 32768 token rows; configs[3]'s
+attention grid: batch 8 x 16 heads x seq 2048), through the C ABI against the CPU oracle.
+
+The other GPU test files check every kernel at sizes the oracle finishes in a blink; none of them launches more attention
+workgroups than the chip has CUs, and the model tests stop at 2 sequences.  Here the launches are the bench's own - attention
+grids of 1536 / 3072 workgroups (two resident per CU, heavy-first dispatch), the fused GEMM epilogues at M = 32768,
+cross-entropy at 32768 x 50280 - and the oracle is evaluated in slices (a batch row, a block of token rows, two sequences at
+a time) so that the host never holds more than a few GB.  Every slice is exact: attention rows, cross-entropy rows and the
+per-sequence terms of a mean loss do not interact.
+
+Tolerances (relative to the reference tensor's max magnitude, as in test_kernels_gpu.py):
+  bf16 outputs 1.6e-2, bf16 attention gradients 2e-2, loss 1e-4 relative (north star), parameter gradients 6e-2 vs the fp32
+  oracle (bf16 activations; the measured worst case is printed).
+"""
+
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O  # noqa: E402
+
+LOSS_RTOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from plainlm_amd import ops as _ops
+  torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+  return _ops
+
+
+def bf(x):
+  return x.to(torch.bfloat16)
+
+
+def relerr(a, ref):
+  a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+  return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def _random_docs(B, T, seed, mean_len=256):
+  """docs_lengths per row summing to T + 1 (data_prep_utils.py:52-77), geometric lengths."""
+  rng = np.random.default_rng(seed)
+  out = []
+  for _ in range(B):
+    lens, tot = [], 0
+    while tot < T + 1:
+      n = int(min(rng.geometric(1.0 / mean_len), T + 1 - tot))
+      lens.append(n)
+      tot += n
+    out.append(lens)
+  return out
+
+
+# --------------------------------------------------------------------------------------
+# (a) attention at the bench's grids: every (batch row, head) against the oracle
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,T,nh,masked', [(32, 1024, 12, False), (32, 1024, 12, True), (8, 2048, 16, False)])
+def test_attention_bench_grid_vs_oracle(ops, B, T, nh, masked):
+  """models/transformer.py:61-63 at config/config.yaml's micro_batch_size 32 (and tr_420M_x8gpu.yaml's 8 x 16 heads x 2048):
+  forward output and dQ / dK / dV of ALL B * nh heads, the oracle evaluated one batch row at a time; two runs bit-equal
+  (the kernels are deterministic: no atomics)."""
+  g = torch.Generator().manual_seed(B * T + nh + masked)
+  d = nh * 64
+  qkv = bf(torch.randn(B * T, 3 * d, generator=g))
+  dout = bf(torch.randn(B * T, d, generator=g))
+  ds = O.doc_start_from_lengths(_random_docs(B, T, 17), T) if masked else None
+  cos, sin = O.rope_table(64, T)
+  cg, sg = cos.cuda(), sin.cuda()
+  dsg = None if ds is None else ds.cuda()
+  qrot = ops.rope_qk_(qkv.cuda(), cg, sg, B, T, nh)
+  out, lse = ops.attn_fwd(qrot, B, T, nh, dsg)
+  dqkv = ops.attn_bwd(qrot, out, dout.cuda(), lse, cg, sg, B, T, nh, dsg)
+  out2, lse2 = ops.attn_fwd(qrot, B, T, nh, dsg)
+  dqkv2 = ops.attn_bwd(qrot, out2, dout.cuda(), lse2, cg, sg, B, T, nh, dsg)
+  assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(dqkv, dqkv2)
+  out_c, dqkv_c = out.float().cpu(), dqkv.float().cpu()
+  worst = {'out': 0.0, 'dq': 0.0, 'dk': 0.0, 'dv': 0.0}
+  for b in range(B):
+    rows = slice(b * T, (b + 1) * T)
+    leaf = qkv[rows].float().requires_grad_(True)
+    q, k, v = (t.reshape(1, T, nh, 64) for t in leaf.split(d, dim=1))
+    ref = O.attention(O.rope_apply(q, cos, sin), O.rope_apply(k, cos, sin), v, None if ds is None else ds[b:b + 1]).reshape(T, d)
+    ref.backward(dout[rows].float())
+    worst['out'] = max(worst['out'], relerr(out_c[rows], ref))
+    for i, n in enumerate(('dq', 'dk', 'dv')):
+      worst[n] = max(worst[n], relerr(dqkv_c[rows, i * d:(i + 1) * d], leaf.grad[:, i * d:(i + 1) * d]))
+  print(f'attention B={B} T={T} nh={nh} masked={masked}: worst rel-to-max per batch row {worst}')
+  assert worst['out'] <= 1.6e-2, worst
+  assert max(worst['dq'], worst['dk'], worst['dv']) <= 2e-2, worst
+
+
+# --------------------------------------------------------------------------------------
+# (b) the fused launches at their in-step shapes
+# --------------------------------------------------------------------------------------
+M160, D160, H160, V160 = 32768, 768, 2048, 50280
+
+
+def test_fc1_swiglu_bench_shape_vs_oracle(ops):
+  """models/components.py:53-56 at (M, h, K) = (32768, 2048, 768): u against a HOST fp32 matmul, act against the oracle's
+  SwiGLU of the bf16 u, and both bit-equal to GEMM + stand-alone kernel."""
+  g = torch.Generator().manual_seed(1)
+  x = bf(torch.randn(M160, D160, generator=g))
+  w = bf(0.05 * torch.randn(2 * H160, D160, generator=g))
+  u, act = ops.fc1_swiglu(x.cuda(), w.cuda())
+  ref_u = x.float() @ w.float().t()
+  assert relerr(u.float(), ref_u) <= 6e-3
+  assert relerr(act.float(), O.swiglu(u.float().cpu(), H160)) <= 1.6e-2
+  u2 = ops.gemm_nt(x.cuda(), w.cuda())
+  assert torch.equal(u, u2) and torch.equal(act, ops.swiglu_fwd(u2))
+
+
+def test_fc2_dx_swiglu_bwd_bench_shape_vs_oracle(ops):
+  """The dX GEMM of fc2 with the SwiGLU backward in its epilogue at (32768, 2048, 768): against autograd through the oracle's
+  SwiGLU with d(act) from a HOST fp32 matmul; bit-equal to GEMM + stand-alone kernel."""
+  g = torch.Generator().manual_seed(2)
+  dy = bf(torch.randn(M160, D160, generator=g))
+  w2t = bf(0.05 * torch.randn(H160, D160, generator=g))
+  u = bf(torch.randn(M160, 2 * H160, generator=g))
+  du = ops.fc2_dx_swiglu_bwd(dy.cuda(), w2t.cuda(), u.cuda())
+  dact = bf(dy.float() @ w2t.float().t()).float()  # the bf16 value the un-fused GEMM stores
+  leaf = u.float().requires_grad_(True)
+  O.swiglu(leaf, H160).backward(dact)
+  assert relerr(du.float(), leaf.grad) <= 1.6e-2
+  assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(dy.cuda(), w2t.cuda()), u.cuda()))
+
+
+def test_qkv_rope_bench_shape_vs_oracle(ops):
+  """models/transformer.py:42-47 at (B, T, nh, K) = (32, 1024, 12, 768)."""
+  B, T, nh, K = 32, 1024, 12, 768
+  d = nh * 64
+  g = torch.Generator().manual_seed(3)
+  x = bf(torch.randn(B * T, K, generator=g))
+  w = bf(0.1 * torch.randn(3 * d, K, generator=g))
+  cos, sin = O.rope_table(64, T)
+  y = x.float() @ w.float().t()
+  q, k, v = (t.reshape(B, T, nh, 64) for t in y.split(d, dim=1))
+  ref = torch.cat([O.rope_apply(q, cos, sin).reshape(B * T, d), O.rope_apply(k, cos, sin).reshape(B * T, d), v.reshape(B * T, d)], dim=1)
+  got = ops.qkv_rope(x.cuda(), w.cuda(), cos.cuda(), sin.cuda(), B, T, nh)
+  assert relerr(got.float(), ref) <= 8e-3
+  two = ops.gemm_nt(x.cuda(), w.cuda())
+  ops.rope_qk_(two, cos.cuda(), sin.cuda(), B, T, nh)
+  assert torch.equal(got, two)
+
+
+def test_cross_entropy_bench_shape_vs_oracle(ops):
+  """engine/engine.py:81,111 at (M, V) = (32768, 50280) on the lm_head's padded rows (ld = 50304): mean loss and the in-place
+  dlogits, the oracle evaluated on blocks of 2048 rows (rows do not interact)."""
+  M, V, ld = M160, V160, 50304
+  g = torch.Generator(device='cuda').manual_seed(4)
+  buf = torch.empty((M, ld), dtype=torch.bfloat16, device='cuda')
+  buf[:, :V] = bf(3 * torch.randn(M, V, generator=g, device='cuda'))
+  buf[:, V:] = 7.0
+  tgt = torch.randint(0, V, (M,), generator=g, device='cuda')
+  logits = buf[:, :V].cpu()
+  rows = ops.ce_fwd_bwd_(buf, tgt, 1.0 / M, V=V)
+  loss = ops.mean(rows).item()
+  assert (buf[:, V:] == 0).all()
+  tc = tgt.cpu()
+  tot, worst = 0.0, 0.0
+  for r0 in range(0, M, 2048):
+    leaf = logits[r0:r0 + 2048].float().requires_grad_(True)
+    l = O.cross_entropy(leaf, tc[r0:r0 + 2048])
+    (l * (2048.0 / M)).backward()
+    tot += l.item() * 2048.0 / M
+    worst = max(worst, relerr(buf[r0:r0 + 2048, :V].float(), leaf.grad))
+  print(f'cross-entropy 32768 x 50280: loss gpu {loss:.6f} oracle {tot:.6f}, dlogits worst rel-to-max {worst:.2e}')
+  assert abs(loss - tot) <= 2e-6 * abs(tot) + 1e-6
+  assert worst <= 8e-3
+
+
+def test_add_rmsnorm_bench_shape_vs_oracle(ops):
+  """models/components.py:22-28 + the residual add of transformer.py:81-82 at (32768, 768), forward and backward."""
+  g = torch.Generator().manual_seed(5)
+  M, d = M160, D160
+  x = torch.randn(M, d, generator=g)
+  w = 1 + 0.1 * torch.randn(d, generator=g)
+  br = bf(0.5 * torch.randn(M, d, generator=g))
+  dy = bf(torch.randn(M, d, generator=g))
+  gin = torch.randn(M, d, generator=g)
+  rr = (x + br.float()).requires_grad_(True)
+  ww = w.clone().requires_grad_(True)
+  yref = O.rmsnorm(rr, ww)
+  yref.backward(dy.float())
+  xout, y, rstd = ops.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-6, branch=br.cuda())
+  assert relerr(xout, rr) <= 1e-7 and relerr(y.float(), yref) <= 6e-3
+  dx, dxb, dw = ops.rmsnorm_bwd(dy.cuda(), xout, w.cuda(), rstd, gin=gin.cuda(), want_bf16=True)
+  assert relerr(dx, rr.grad + gin) <= 2e-5 and torch.equal(dxb, dx.bfloat16())
+  assert relerr(dw, ww.grad) <= 1e-4  # 32768-term fp32 column sums in a different order
+
+
+# --------------------------------------------------------------------------------------
+# (c) one full 160M step at batch 32: loss and ALL 75 gradients
+# --------------------------------------------------------------------------------------
+def test_160m_batch32_loss_and_all_gradients_vs_oracle(ops):
+  """BASELINE configs[1] exactly as bench.py runs it (12L, d=768, 12 heads, V=50280, batch 32 x seq 1024, config/config.yaml
+  micro_batch_size 32): loss within 1e-4 relative of the fp32 CPU oracle and every one of the 75 parameter gradients.  The
+  oracle's loss is the mean over sequences and its gradients the mean of per-pair gradients, so it is evaluated two sequences
+  at a time (16 fwd+bwd passes of the restatement, ~4 s each) and averaged."""
+  import plainlm_amd as P
+  ocfg = O.OracleConfig(vocab_size=V160, seq_len=1024, dim=768, n_layers=12, n_heads=12)
+  w = O.init_params(ocfg, seed=21)
+  rng = np.random.default_rng(2024)
+  tok = torch.from_numpy(rng.integers(0, V160, size=(32, 1025)))
+  ids, tgt = tok[:, :1024], tok[:, 1:]
+  m = P.Transformer(P.ModelConfig(vocab_size=V160, seq_len=1024, dim=768, expand=8 / 3, n_layers=12, n_heads=12, mlp='glu'))
+  m.load_state_dict(w)
+  m = m.cuda()
+  m.enable_main_grad()
+  m.sink.begin_window()
+  loss = m.loss(ids.cuda(), tgt.cuda())
+  loss.backward()
+  m.attach_grads()
+  got = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+  lg = loss.item()
+  del m
+  torch.cuda.empty_cache()
+  oloss, og = 0.0, None
+  for b0 in range(0, 32, 2):
+    l, gr = O.loss_and_grads(w, ocfg, ids[b0:b0 + 2], tgt[b0:b0 + 2], scale=1.0 / 16)
+    oloss += l.item() / 16
+    if og is None:
+      og = gr
+    else:
+      for n in og:
+        og[n].add_(gr[n])
+  rel = abs(lg - oloss) / abs(oloss)
+  print(f'160M batch-32 loss gpu {lg:.6f} cpu {oloss:.6f} rel {rel:.2e}')
+  assert rel <= LOSS_RTOL
+  assert len(got) == 75
+  worst = {n: relerr(got[n], og[n]) for n in got}
+  top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+  print('160M batch-32 gradients vs fp32 oracle (rel-to-max), worst five:', [(n, f'{e:.1e}') for n, e in top])
+  bad = {n: e for n, e in worst.items() if e > 6e-2}
+  assert not bad, bad

@@ -276,7 +276,7 @@ def test_160m_engine_three_optimizer_steps_vs_oracle(P):
 
 def test_420m_loss_and_grad_parity_vs_oracle(P):
   """BASELINE configs[3] model (config/tr_420M_x8gpu.yaml:20-24,34: 24L, d=1024, 16 heads, expand 8/3 -> h=2816, seq 2048)
-  on one sequence: bf16 GPU loss vs fp32 CPU oracle within 1e-4 relative; six gradients compared."""
+  on one sequence: bf16 GPU loss vs fp32 CPU oracle within 1e-4 relative; all 147 gradients compared."""
   ocfg = O.OracleConfig(vocab_size=50280, seq_len=2048, dim=1024, n_layers=24, n_heads=16)
   assert ocfg.hidden == 2816
   w = O.init_params(ocfg, seed=5)
@@ -296,10 +296,11 @@ def test_420m_loss_and_grad_parity_vs_oracle(P):
   rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
   print(f'420M loss gpu {loss.item():.6f} cpu {oloss.item():.6f} rel {rel:.2e}')
   assert rel <= LOSS_RTOL
-  for n in ('lm_head.weight', 'out_norm.weight', 'layers.23.mlp.fc2.weight', 'layers.0.attn.w_qkv.weight',
-            'layers.12.mlp_norm.weight', 'embed_tokens.weight'):
-    g = dict(m.named_parameters())[n].grad
-    assert relmax(g, og[n]) < 6e-2, (n, relmax(g, og[n]))
+  worst = {n: relmax(p.grad, og[n]) for n, p in m.named_parameters()}
+  assert len(worst) == 147  # 6 per block + embed_tokens, out_norm, lm_head: every gradient, not a sample
+  print('420M gradients vs fp32 oracle, worst five:', [(n, f'{e:.1e}') for n, e in sorted(worst.items(), key=lambda kv: -kv[1])[:5]])
+  bad = {n: e for n, e in worst.items() if e > 6e-2}
+  assert not bad, bad
 
 
 def test_160m_docmask_engine_step_vs_oracle(P):
@@ -504,7 +505,7 @@ def test_eval_mean_over_batches(P, mdl):
 
 def test_160m_loss_and_grad_parity_vs_oracle(P):
   """BASELINE configs[1] shape (12L, d=768, 12 heads, V=50280, seq 1024) on 2 sequences:
-  bf16 GPU loss vs fp32 CPU oracle within 1e-4 relative; a few gradients compared too."""
+  bf16 GPU loss vs fp32 CPU oracle within 1e-4 relative; all 75 gradients compared."""
   ocfg = O.OracleConfig(vocab_size=50280, seq_len=1024, dim=768, n_layers=12, n_heads=12)
   w = O.init_params(ocfg, seed=7)
   rng = np.random.default_rng(1234)
@@ -522,10 +523,11 @@ def test_160m_loss_and_grad_parity_vs_oracle(P):
   rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
   print(f'160M loss gpu {loss.item():.6f} cpu {oloss.item():.6f} rel {rel:.2e}')
   assert rel <= LOSS_RTOL
-  for n in ('lm_head.weight', 'out_norm.weight', 'layers.11.mlp.fc2.weight', 'layers.0.attn.w_qkv.weight',
-            'layers.5.attn_norm.weight', 'embed_tokens.weight'):
-    g = dict(m.named_parameters())[n].grad
-    assert relmax(g, og[n]) < 6e-2, (n, relmax(g, og[n]))
+  worst = {n: relmax(p.grad, og[n]) for n, p in m.named_parameters()}
+  assert len(worst) == 75  # every gradient, not a sample
+  print('160M gradients vs fp32 oracle, worst five:', [(n, f'{e:.1e}') for n, e in sorted(worst.items(), key=lambda kv: -kv[1])[:5]])
+  bad = {n: e for n, e in worst.items() if e > 6e-2}
+  assert not bad, bad
 
 
 def test_rccl_reducer_single_rank(P, mdl):
