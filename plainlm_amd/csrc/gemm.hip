@@ -310,7 +310,7 @@ extern "C" int plm_gemm_bf16_nt_ws(const uint16_t* A, int64_t lda, const uint16_
                                    int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   PLM_REQUIRE(A && B && C, "plm_gemm_bf16_nt: null pointer");
-  PLM_REQUIRE(variant >= 0 && variant <= 6, "plm_gemm_bf16_nt_ex: variant must be 0..6");
+  PLM_REQUIRE(variant >= 0 && variant <= 7, "plm_gemm_bf16_nt_ex: variant must be 0..7");
   PLM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "plm_gemm_bf16_nt: bad shape M=%ld N=%ld K=%ld",
               (long)M, (long)N, (long)K);
   PLM_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "plm_gemm_bf16_nt: K, lda, ldb must be multiples of 8 and ldc of 4 (K=%ld lda=%ld ldb=%ld ldc=%ld)",

@@ -72,6 +72,18 @@ extern "C" int plm_set_cu_reserve(int n) {
   return PLM_OK;
 }
 
+static bool ensure_num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return true;
+}
+// for gemm_duo.hip: one slot per CU outside the reserve (0 when the device cannot be queried)
+int plm_persistent_slots() { return ensure_num_cus() ? persistent_slots() : 0; }
+
 static double round_efficiency(int64_t tiles, int slots) {
   const int64_t rounds = (tiles + slots - 1) / slots;
   return (double)tiles / (double)(rounds * slots);
@@ -1197,6 +1209,11 @@ static bool aligned16(std::initializer_list<const void*> ptrs) {
   return (v & 15) == 0;
 }
 
+// gemm_duo.hip: two 4-wave workgroups per CU on 256x128 tiles; epi 0 plain | 1 SwiGLU forward | 2 SwiGLU backward | 3 RoPE
+bool plm_launch_gemm_nt_duo(int epi, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
+                            int64_t N, int64_t K, const float* alpha_dev, uint16_t* act, int64_t ldact, const float* rcos,
+                            const float* rsin, int64_t T, int64_t rope_cols, hipStream_t s);
+
 // fc1 + SwiGLU in one launch (see GLU above).  Returns false when the shape does not qualify (the caller then runs the GEMM and
 // plm_swiglu_fwd separately - same bits).
 bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, uint16_t* act,
@@ -1207,6 +1224,7 @@ bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, i
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (plm_env().nt_duo > 0 && (plm_env().nt_duo & 1) && plm_launch_gemm_nt_duo(1, A, lda, B, ldb, C, ldc, M, N, K, nullptr, act, ldact, nullptr, nullptr, 0, 0, s)) return true;
   if (K % 64 != 0 || N % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldact % 8 != 0) return false;
   if (!aligned16({A, B, C, act})) return false;
   const int tm = (int)plm_cdiv(M, 256), tn = (int)(N / 256);
@@ -1227,6 +1245,9 @@ bool plm_launch_gemm_nt_glub(const uint16_t* A, int64_t lda, const uint16_t* B, 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (plm_env().nt_duo > 0 && (plm_env().nt_duo & 2) &&
+      plm_launch_gemm_nt_duo(2, A, lda, B, ldb, DU, lddu, M, h, K, nullptr, const_cast<uint16_t*>(U), ldu, nullptr, nullptr, 0, 0, s))
+    return true;
   if (K % 64 != 0 || h % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldu % 4 != 0 || lddu % 8 != 0) return false;
   if (!aligned16({A, B, DU}) || (reinterpret_cast<uintptr_t>(U) & 7) != 0) return false;  // U is read in 8-byte pieces
   const int tm = (int)plm_cdiv(M, 256), tn = (int)(h / 256);
@@ -1247,6 +1268,7 @@ bool plm_launch_gemm_nt_rope(const uint16_t* A, int64_t lda, const uint16_t* B, 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (plm_env().nt_duo > 0 && (plm_env().nt_duo & 4) && plm_launch_gemm_nt_duo(3, A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, rcos, rsin, T, rope_cols, s)) return true;
   if (K % 64 != 0 || N % 8 != 0 || M < 512 || N < 128 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
   if (!aligned16({A, B, C, rcos, rsin})) return false;
   const int tm = (int)plm_cdiv(M, 256);
@@ -1288,6 +1310,7 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (variant == 7) return plm_launch_gemm_nt_duo(0, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, nullptr, 0, nullptr, nullptr, 0, 0, s);
   const int tm = (int)plm_cdiv(M, 256);
   const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
   const int slots = persistent_slots();

@@ -27,6 +27,9 @@ static void load_env() {
   g_env.tn_no_big = getenv("PLM_TN_NO_BIG") != nullptr;
   g_env.nt_no_hybrid = getenv("PLM_NT_NO_HYBRID") != nullptr;
   g_env.nt_hybrid_min_k = num("PLM_NT_HYBRID_MIN_K");
+  g_env.nt_duo = (int)num("PLM_NT_DUO");
+  g_env.duo_stagger_us = getenv("PLM_DUO_STAGGER_US") ? atof(getenv("PLM_DUO_STAGGER_US")) : -1.0;
+  g_env.duo_dbg = getenv("PLM_DUO_DBG") ? atoi(getenv("PLM_DUO_DBG")) : 0;
 }
 const PlmEnv& plm_env() {
   static const bool once = (load_env(), true);

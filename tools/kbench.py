@@ -133,6 +133,47 @@ def main():
         ops.reload_env()
       del A, Bm, out
 
+  if want('duo'):
+    # the two-workgroups-per-CU 256x128 family (gemm_duo.hip) against the one-workgroup-per-CU kernels, same process, interleaved
+    from oracle import cpu_ref as O_
+    cos, sin = (t.cuda() for t in O_.rope_table(64, T))
+    A = torch.randn(M, d, device=dev).to(BF)
+    W1 = (torch.randn(2 * h, d, device=dev) * 0.02).to(BF)
+    W2T = (torch.randn(h, d, device=dev) * 0.02).to(BF)
+    Um = torch.randn(M, 2 * h, device=dev).to(BF)
+    Wq = (torch.randn(3 * d, d, device=dev) * 0.02).to(BF)
+    Wo = (torch.randn(d, d, device=dev) * 0.02).to(BF)
+    outo = torch.empty(M, d, device=dev, dtype=BF)
+    cases = {'fc1 + swiglu': (lambda: ops.fc1_swiglu(A, W1), 2.0 * M * 2 * h * d),
+             'dX fc2 + swiglu bwd': (lambda: ops.fc2_dx_swiglu_bwd(A, W2T, Um), 2.0 * M * h * d),
+             'qkv + rope': (lambda: ops.qkv_rope(A, Wq, cos, sin, B, T, nh), 2.0 * M * 3 * d * d)}
+    def setenv(**kv):
+      for k, v in kv.items():
+        if v is None:
+          os.environ.pop(k, None)
+        else:
+          os.environ[k] = v
+      ops.reload_env()
+    for rnd in range(2):
+      for name, (fn, fl) in cases.items():
+        setenv(PLM_NT_DUO='0', PLM_DUO_STAGGER_US=None)
+        rec(f'{name} [1 wg/cu] r{rnd}', timeit(fn, a.iters), flops=fl)
+        for stg in (None, '0', '2', '4', '6', '9'):
+          setenv(PLM_NT_DUO='7', PLM_DUO_STAGGER_US=stg)
+          rec(f'{name} [duo stagger {stg}] r{rnd}', timeit(fn, a.iters), flops=fl)
+      setenv(PLM_NT_DUO=None, PLM_DUO_STAGGER_US=None)
+      for name, (m, n, k) in {'nt out fwd': (M, d, d), 'nt qkv fwd': (M, 3 * d, d), 'nt fc1 fwd': (M, 2 * h, d), 'nt dX fc2': (M, h, d), 'nt fc2 fwd': (M, d, h)}.items():
+        X = torch.randn(m, k, device=dev).to(BF)
+        W = (torch.randn(n, k, device=dev) * 0.02).to(BF)
+        o = torch.empty(m, n, device=dev, dtype=BF)
+        rec(f'{name} [auto] r{rnd}', timeit(lambda: ops.gemm_nt(X, W, out=o), a.iters), flops=2.0 * m * n * k)
+        for stg in (None, '0', '4'):
+          setenv(PLM_DUO_STAGGER_US=stg)
+          rec(f'{name} [duo stagger {stg}] r{rnd}', timeit(lambda: ops.gemm_nt(X, W, out=o, variant=7), a.iters), flops=2.0 * m * n * k)
+        setenv(PLM_DUO_STAGGER_US=None)
+        del X, W, o
+    del A, W1, W2T, Um, Wq, Wo, outo
+
   if want('gemm'):
     shp = [(d, h), (2 * h, d), (d, d), (3 * d, d)]  # fc2, fc1, w_out, w_qkv: the dW GEMMs of one block
     As = [torch.randn(M, m, device=dev).to(BF) for m, _ in shp]
