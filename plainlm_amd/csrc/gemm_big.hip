@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
             const int row = c >> 3, ch = c & 7;  // rows 0-15: d(gate), 16-31: d(up) of output row row & 15
             const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
             const int gm = mrow0 + sr * 16 + (row & 15);
-            if (gm < M) st_bf16x8(C + (int64_t)gm * ldc + (row >> 4) * N + n0 + wn * TN + ch * 8, v);
+            if (gm < M) st_c2_bf16x8(C + (int64_t)gm * ldc + (row >> 4) * N + n0 + wn * TN + ch * 8, v);
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -527,12 +527,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           if (ROPE) {
             if (gm < M && gn < ea.rope_cols) {  // a q / k chunk: four pairs of head dims (gn % 64) / 2 .. + 3 at position gm % T
               const int tab = (gm % ea.T) * 32 + ((gn & 63) >> 1);
-              st_bf16x8(C + (int64_t)gm * ldc + gn, rope8(v, *reinterpret_cast<const f32x4_t*>(ea.rcos + tab),
+              st_c2_bf16x8(C + (int64_t)gm * ldc + gn, rope8(v, *reinterpret_cast<const f32x4_t*>(ea.rcos + tab),
                                                           *reinterpret_cast<const f32x4_t*>(ea.rsin + tab), 1.f));
               continue;
             }
           }
-          if (gm < M && gn < N) st_bf16x8(C + (int64_t)gm * ldc + gn, v);
+          if (gm < M && gn < N) st_c_bf16x8(C + (int64_t)gm * ldc + gn, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
           const int row = c >> 2, ch = c & 3;
           const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
           const int gm = mrow0 + row;
-          if (gm < M) st_bf16x8(act + (int64_t)gm * ldact + n0 / 2 + wn * 32 + ch * 8, v);
+          if (gm < M) st_c2_bf16x8(act + (int64_t)gm * ldact + n0 / 2 + wn * 32 + ch * 8, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
           if (row >= Mo) continue;
           float* dst = out + (int64_t)row * ld + col;
           const float v = acc4[f][j][r] * scl;
-          *dst = rmw ? *dst + v : v;
+          *dst = rmw ? *dst + v : v;  // (`nt` on these stores: -0.1 % in the step, profiles/r04_ab_stores.txt)
         }
       }
     }

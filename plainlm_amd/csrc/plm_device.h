@@ -80,6 +80,33 @@ __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // v_cvt_
 // 16-byte global load / store of 8 bf16
 __device__ __forceinline__ bf16x8_t ld_bf16x8(const uint16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 __device__ __forceinline__ void st_bf16x8(uint16_t* p, bf16x8_t v) { *reinterpret_cast<bf16x8_t*>(p) = v; }
+// Store of a GEMM output row segment.  PLM_C_STORE_MODE: 0 plain | 1 `sc1` (the line does not stay in the XCD's L2:
+// MI355X_MICROARCH.md, stores of each flavour) | 2 `nt` (default).  Same-box A/Bs of the whole step (profiles/r04_ab_stores.txt):
+// sc1 -0.6 %, nt +0.6 % (the outputs are 50 MB - 3.3 GB streams that only push operand panels out of the 4 MB L2), nt on the fused
+// epilogues' extra outputs as well (st_c2_bf16x8) -0.5 % against nt on C alone.
+#ifndef PLM_C_STORE_MODE
+#define PLM_C_STORE_MODE 2
+#endif
+__device__ __forceinline__ void st_c_bf16x8(uint16_t* p, bf16x8_t v) {
+#if PLM_C_STORE_MODE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif PLM_C_STORE_MODE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<bf16x8_t*>(p) = v;
+#endif
+}
+// the fused epilogues' extra outputs (d(gate) | d(up), rotated q | k, the SwiGLU activation): PLM_C_STORE_ALL = 1 gives them the mode above
+#ifndef PLM_C_STORE_ALL
+#define PLM_C_STORE_ALL 0
+#endif
+__device__ __forceinline__ void st_c2_bf16x8(uint16_t* p, bf16x8_t v) {
+#if PLM_C_STORE_ALL
+  st_c_bf16x8(p, v);
+#else
+  *reinterpret_cast<bf16x8_t*>(p) = v;
+#endif
+}
 __device__ __forceinline__ bf16x4_t ld_bf16x4(const uint16_t* p) { return *reinterpret_cast<const bf16x4_t*>(p); }
 __device__ __forceinline__ void st_bf16x4(uint16_t* p, bf16x4_t v) { *reinterpret_cast<bf16x4_t*>(p) = v; }
 
