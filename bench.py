@@ -265,9 +265,12 @@ def main():
     comm = ddp.make_comm(device, a.comm)
     comm_tail = ddp.make_tail_comm(comm)
     reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
-                              reserve_cus=ddp.COMM_CUS if force_reducer else None, writers=model.grad_writers(), comm_tail=comm_tail)
+                              reserve_cus=ddp.COMM_CUS if force_reducer else None, writers=model.grad_writers(), comm_tail=comm_tail,
+                              groups=model.grad_groups())
     reducer.broadcast_params([p.data for p in params])
     model.sink.on_ready = reducer.param_ready
+    model.sink.on_queued = reducer.param_queued
+    model.sink.resolve_queue_budget(device, agreed=ddp.agree_min(model.sink.resolve_queue_budget(device)))
 
   # synthetic tokens: rank r takes rows r, r+W, ... (DistributedSampler(shuffle=False) order)
   n_pool = 4
@@ -344,6 +347,9 @@ def main():
   if reducer is not None:  # which data plane actually ran (make_comm may fall back from direct RCCL to torch's nccl backend)
     out['comm'] = {'backend': reducer.comm.backend, 'ranks': reducer.comm.world_size, 'buckets': len(reducer.buckets),
                    'bucket_cap_mb': a.bucket_mb, 'cu_reserve': reducer.reserve_cus,
+                   'reserve_policy': 'only inside a window of estimated GPU time behind each bucket launch (length: the bucket\'s collective in the previous step'
+                                     + (f', here modelled at {reducer.model_gbps} GB/s' if reducer.model_gbps else '') + ')',
+                   'bucket_ms': [round(1e3 * s, 3) for s in reducer.bucket_secs],
                    'max_ctas_overlapped_buckets': getattr(reducer.comm, 'max_ctas', None),
                    'tail_communicator': 'uncapped split' if reducer.comm_tail is not None else 'none (tail bucket on the same communicator)',
                    'nccl_max_nchannels_env': os.environ.get('NCCL_MAX_NCHANNELS')}
@@ -381,8 +387,10 @@ def main():
       opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
       if reducer is not None:
         reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
-                                  reserve_cus=reducer.reserve_cus, writers=model.grad_writers(), comm_tail=reducer.comm_tail)
+                                  reserve_cus=reducer.reserve_cus, writers=model.grad_writers(), comm_tail=reducer.comm_tail,
+                                  groups=model.grad_groups())
         model.sink.on_ready = reducer.param_ready
+        model.sink.on_queued = reducer.param_queued
 
       def full(i):
         fwd_bwd(i)

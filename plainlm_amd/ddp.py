@@ -20,13 +20,17 @@ import torch.distributed as dist
 from . import _lib
 
 
-# CUs kept free for RCCL's kernels while gradient buckets are in flight, and the matching cap on RCCL channels (one
-# workgroup each).  The persistent GEMMs launch one workgroup per CU; a workgroup that finds its CU taken by a collective
-# would run after the others (a second round), so the GEMM grids shrink by this many while - and only while - an
-# all-reduce may be running: GradReducer sets the reserve when the first bucket of a step is launched and clears it in
-# finish(), so the forward pass and the lm_head backward (no collective in flight) keep all 256 CUs (the reserve costs
-# 5.5 % on the GEMMs it applies to, run 30).
-COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
+# CUs kept free for RCCL's kernels while a gradient bucket's collective is running, and the matching cap on RCCL channels (one
+# workgroup each; 0 = no reserve and RCCL's own channel count).  The persistent GEMMs launch one workgroup per CU; a workgroup that
+# finds its CU taken by a collective would run after the others (a second round), so the GEMM grids shrink by this many while - and
+# only while - an all-reduce is expected to be in flight (GradReducer: a window of estimated GPU time behind every bucket launch,
+# its length the bucket's measured duration in the previous step); the forward pass, the lm_head backward and every GEMM behind a
+# finished collective keep all 256 CUs.  Sizing: 649 MB of fp32 gradients per ~20 ms of backward is 32 GB/s of algorithm bandwidth
+# = 57 GB/s of bus bandwidth at 8 ranks; one RCCL channel moves 15-25 GB/s over an xGMI link, so 8 channels cover it twice over.
+# The reserve costs the GEMMs it applies to ~1 % per 4 CUs (profiles/r04_ddp_whatif.txt).
+COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '8'))
+# Estimated rates (flop/s) by kernel family, for the reducer's clock of enqueued GPU time (bench.py's roofline families, round 3)
+_FAMILY_RATE = {'gemm_nt': 1.15e15, 'gemm_nt_fused': 0.85e15, 'gemm_tn': 1.15e15, 'attn_fwd': 0.55e15, 'attn_bwd': 0.36e15}
 # The cap is set twice for world > 1: PER COMMUNICATOR (ncclConfig_t.maxCTAs through plm_comm_init_capped) and, before the first
 # RCCL call of the process, as NCCL_MAX_NCHANNELS (unless the caller has set it) - the per-communicator form has only ever run with ONE
 # rank (tests/test_model_gpu.py::test_rccl_capped_communicator_and_split_tail_single_rank), and the environment variable is also
@@ -47,7 +51,7 @@ class RcclComm:
   def __init__(self, rank, world_size, device_index, store_group=None, max_ctas=None, _handle=None):
     lib = _lib.load()
     self.lib, self.rank, self.world_size, self.device_index = lib, rank, world_size, device_index
-    self.max_ctas = (COMM_CUS if world_size > 1 else 0) if max_ctas is None else int(max_ctas)
+    self.max_ctas = (max(COMM_CUS, 0) if world_size > 1 else 0) if max_ctas is None else int(max_ctas)
     self.backend = 'rccl-direct'
     if _handle is not None:  # split()
       self.handle = _handle
@@ -115,15 +119,30 @@ class TorchDistComm:
     pass
 
 
-def plan_buckets(spans, cap_bytes):
+def plan_buckets(spans, cap_bytes, groups=None):
   """spans: [(offset, numel)] per parameter (any order, together tiling the flat buffer without gaps).
   Returns buckets as (lo, hi, [param idx]): contiguous regions of the flat buffer, built from its END backwards
   (the flat layout follows parameters() order, so the end holds the gradients that become ready first), each at
-  most cap_bytes unless a single parameter is larger (it then forms its own bucket)."""
+  most cap_bytes unless a single parameter is larger (it then forms its own bucket).
+  groups: optional lists of parameter indices that belong together (the Linear weights of one transformer block: their
+  gradients come out of ONE grouped dW launch).  A group that fits a bucket is never split across two: the walk closes the
+  current bucket in front of a group that would not fit into the rest of it."""
   order = sorted(range(len(spans)), key=lambda i: spans[i][0], reverse=True)
+  group_of, group_bytes = {}, {}
+  for gi, g in enumerate(groups or []):
+    for i in g:
+      group_of[i] = gi
+    group_bytes[gi] = sum(spans[i][1] for i in g) * 4
+  seen_groups = set()
   buckets, cur, cur_bytes = [], [], 0
   for idx in order:
     nbytes = spans[idx][1] * 4
+    gi = group_of.get(idx)
+    if gi is not None and gi not in seen_groups:  # first (= highest) member of its group
+      seen_groups.add(gi)
+      if cur and group_bytes[gi] <= cap_bytes < cur_bytes + group_bytes[gi]:
+        buckets.append(cur)
+        cur, cur_bytes = [], 0
     if cur and cur_bytes + nbytes > cap_bytes:
       buckets.append(cur)
       cur, cur_bytes = [], 0
@@ -155,8 +174,9 @@ class GradReducer:
   """
 
   def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False, reserve_cus=None,
-               writers=None, comm_tail=None):
-    """writers: optional {id(param): n} = how many backward kernels write that parameter's gradient per backward pass
+               writers=None, comm_tail=None, groups=None):
+    """groups: see plan_buckets (Transformer.grad_groups()).
+    writers: optional {id(param): n} = how many backward kernels write that parameter's gradient per backward pass
     (default 1).  A weight shared by lm_head and embed_tokens (tie_embeddings, models/transformer.py:131-132) has two: the
     head's dW first, the embedding scatter last.  A bucket is launched only when every writer of every member has
     reported; launching after the first would let RCCL reduce the span in place while the second kernel still adds to it."""
@@ -166,7 +186,8 @@ class GradReducer:
     # given (see COMM_CUS): the bucket of params[0] - embed_tokens, whose gradient is the last kernel of backward - and
     # whatever finish() still has to launch.
     self.comm_tail = comm_tail
-    self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)))
+    self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)), groups)
+    self.numel = [n for _, n in spans]
     self.index_of = {id(p): i for i, p in enumerate(params)}
     self.writers = [int((writers or {}).get(id(p), 1)) for p in params]
     if min(self.writers, default=1) < 1:
@@ -183,17 +204,66 @@ class GradReducer:
     self.sync = False
     self.pending = None
     self.launched = []
-    # CUs left to the collectives between the first bucket launch of a step and finish() (see COMM_CUS)
+    # CUs left to the collectives while one is expected to be running (see COMM_CUS).  The host enqueues kernels milliseconds ahead
+    # of the GPU, so "is a collective running when THIS GEMM starts" is answered on a clock of estimated GPU time: every MFMA launch
+    # advances it by flops / its family's rate (ops.LAUNCH_HOOK), a bucket launch opens a window [now or the end of the previous
+    # window, + the bucket's duration], and a launch inside a window shrinks its grid.  A bucket's duration is what its collective
+    # took in the previous step (HIP events on the side stream), before the first measurement bytes / PLM_COMM_MODEL_GBPS (also the
+    # way to ask "what if the links gave X GB/s" on one GPU, where the measured collectives are local copies).
     if reserve_cus is None:
       reserve_cus = COMM_CUS if (self.on_gpu and comm.world_size > 1) else 0
     self.reserve_cus = int(reserve_cus) if self.on_gpu else 0
     self._reserved = False
+    model_gbps = os.environ.get('PLM_COMM_MODEL_GBPS')
+    self.model_gbps = float(model_gbps) if model_gbps else None
+    gbps = self.model_gbps or 60.0
+    self.bucket_secs = [(hi - lo) * 4 / (gbps * 1e9) for lo, hi, _ in self.buckets]
+    self._timing = {}  # bucket -> (start event, end event) of its last collective
+    self.clock, self.window_end = 0.0, -1.0
+    # the dW queue (functional.GradSink) is flushed at bucket boundaries once it holds this many bytes of gradients
+    self.dw_group_bytes = int(float(os.environ.get('PLM_DW_GROUP_MB', '80')) * 1e6)
+    self._queued, self._queued_per_bucket, self._queued_bytes = set(), {}, 0
 
   def begin(self, sync):
     self.sync = bool(sync) and (self.comm.world_size > 1 or self.force)
     self.pending = [sum(self.writers[i] for i in idxs) for (_, _, idxs) in self.buckets]
     self.reports = [0] * len(self.writers)
     self.launched = []
+    self._queued, self._queued_per_bucket, self._queued_bytes = set(), {}, 0
+    self.clock, self.window_end = 0.0, -1.0
+    if self.on_gpu and self.sync:
+      if self.model_gbps is None:
+        for b, (s, e) in list(self._timing.items()):  # last step's collectives (finished: finish() joined the streams)
+          if e.query():
+            self.bucket_secs[b] = 0.5 * self.bucket_secs[b] + 0.5 * s.elapsed_time(e) * 1e-3
+      if self.reserve_cus:
+        from . import ops
+        ops.LAUNCH_HOOK = self._on_launch
+
+  def _on_launch(self, family, flops):
+    """ops.LAUNCH_HOOK: called right before an MFMA kernel is enqueued."""
+    want = self.clock < self.window_end
+    if want != self._reserved:
+      from . import ops
+      ops.set_cu_reserve(self.reserve_cus if want else 0)
+      self._reserved = want
+    self.clock += flops / _FAMILY_RATE.get(family, 1.0e15)
+
+  def param_queued(self, p):
+    """functional.GradSink.on_queued: the weight gradient of p has been queued for a grouped dW launch.  True = launch the group
+    now: the queue holds every outstanding gradient of p's bucket (the bucket can go out as soon as the group has run) and at
+    least dw_group_bytes of gradients (small groups leave most of their tiles to the split-K remainder).  None on
+    micro-steps that do not communicate (the sink's count-based default decides)."""
+    if not self.sync:
+      return None
+    i = self.index_of.get(id(p))
+    if i is None or i in self._queued:
+      return None
+    b = self.bucket_of[i]
+    self._queued.add(i)
+    self._queued_per_bucket[b] = self._queued_per_bucket.get(b, 0) + 1
+    self._queued_bytes += self.numel[i] * 4
+    return self._queued_per_bucket[b] >= self.pending[b] and self._queued_bytes >= self.dw_group_bytes
 
   def _launch(self, b, tail=False):
     lo, hi, _ = self.buckets[b]
@@ -204,11 +274,13 @@ class GradReducer:
       ev.record(torch.cuda.current_stream())
       self.stream.wait_event(ev)
       with torch.cuda.stream(self.stream):
+        t0, t1 = self._timing.get(b) or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        t0.record(self.stream)
         comm.allreduce_avg_(span, self.stream)
-      if self.reserve_cus and not self._reserved:  # GEMMs enqueued from here on may run beside a collective
-        from . import ops
-        ops.set_cu_reserve(self.reserve_cus)
-        self._reserved = True
+        t1.record(self.stream)
+        self._timing[b] = (t0, t1)
+      # GEMMs enqueued inside this window may run beside the collective (see __init__)
+      self.window_end = max(self.window_end, self.clock) + self.bucket_secs[b]
     else:
       comm.allreduce_avg_(span, None)
     self.launched.append(b)
@@ -220,6 +292,10 @@ class GradReducer:
     if i is None:
       return
     b = self.bucket_of[i]
+    if i in self._queued:
+      self._queued.discard(i)
+      self._queued_per_bucket[b] -= 1
+      self._queued_bytes -= self.numel[i] * 4
     self.reports[i] += 1
     if self.reports[i] > self.writers[i]:
       raise RuntimeError(f'GradReducer: parameter {i} reported more gradient writes than declared ({self.writers[i]}); '
@@ -237,10 +313,13 @@ class GradReducer:
         self._launch(b, tail=True)
     if self.on_gpu:
       torch.cuda.current_stream().wait_stream(self.stream)
-    if self._reserved:  # everything enqueued after the join runs with no collective in flight
+    if self.on_gpu:
       from . import ops
-      ops.set_cu_reserve(0)
-      self._reserved = False
+      if ops.LAUNCH_HOOK == self._on_launch:
+        ops.LAUNCH_HOOK = None
+      if self._reserved:  # everything enqueued after the join runs with no collective in flight
+        ops.set_cu_reserve(0)
+        self._reserved = False
     self.sync = False
 
   def broadcast_params(self, flat_params_or_list):
@@ -270,8 +349,17 @@ def make_comm(device, backend=None, group=None):
       return RcclComm(rank, world, idx, store_group=group)
     # The direct communicator is created collectively; if it fails on ANY rank every rank falls back to torch.distributed's
     # nccl (= RCCL) backend, so that a box whose RCCL set-up differs from the build machine still trains.
-    if os.environ.get('PLM_COMM_TAIL', '0') != '1':
-      os.environ.setdefault('NCCL_MAX_NCHANNELS', str(COMM_CUS))  # before ANY RCCL call: RCCL may read it once
+    # Process-wide belt and braces for the per-communicator cap (ncclConfig_t.maxCTAs has only ever run with one rank): ONLY with a
+    # positive cap (0 = RCCL's default channel count; RCCL clamps NCCL_MAX_NCHANNELS=0 to ONE channel), only when the user has not set it,
+    # and not when an uncapped tail communicator is wanted.  It also caps every other RCCL communicator of the process, and has
+    # no effect once RCCL has read its environment - both said out loud.
+    if COMM_CUS > 0 and os.environ.get('PLM_COMM_TAIL', '0') != '1' and 'NCCL_MAX_NCHANNELS' not in os.environ:
+      os.environ['NCCL_MAX_NCHANNELS'] = str(COMM_CUS)
+      late = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+      if rank == 0:
+        print(f'[plainlm_amd.ddp] NCCL_MAX_NCHANNELS={COMM_CUS} set for this process (PLM_COMM_CUS; caps every RCCL communicator created '
+              f'from now on)' + ('; torch.distributed\'s nccl backend is already initialised: RCCL may have read its environment, the '
+                                 'per-communicator maxCTAs is then the only cap' if late else ''), flush=True)
     comm, err = None, None
     try:
       comm = RcclComm(rank, world, idx, store_group=group)
@@ -306,6 +394,16 @@ def make_tail_comm(comm, group=None):
     tail.close()
   print(f'[plainlm_amd.ddp] rank {comm.rank}: no uncapped tail communicator ({err}); the tail bucket uses the capped one', flush=True)
   return None
+
+
+def agree_min(value, group=None):
+  """Minimum of an integer over the ranks (control plane; the value itself without a process group)."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return int(value)
+  dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+  t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+  dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+  return int(t.item())
 
 
 def all_ranks_ok(ok, group=None):

@@ -213,10 +213,14 @@ class HipEngine(torch.nn.Module):
     if dist.is_initialized() and dist.get_world_size() > 1:
       comm = ddp.make_comm(device, comm_backend)
       self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb,
-                                      writers=self.model.grad_writers(), comm_tail=ddp.make_tail_comm(comm))
+                                      writers=self.model.grad_writers(), comm_tail=ddp.make_tail_comm(comm),
+                                      groups=self.model.grad_groups())
       self.reducer.broadcast_params([p.data for p in self.params])  # DDP ctor's _sync_module_states
       self.model.invalidate_shadows()
       self.model.sink.on_ready = self.reducer.param_ready
+      self.model.sink.on_queued = self.reducer.param_queued
+      # every rank flushes its dW queue at the same points (ranks that differ would launch their buckets in different orders)
+      self.model.sink.resolve_queue_budget(device, agreed=ddp.agree_min(self.model.sink.resolve_queue_budget(device)))
 
     if getattr(cfg, 'resume', False):
       self.optimizer.load_state_dict(ckpt['optimizer'])

@@ -24,6 +24,10 @@ class GradSink:
     self.enabled = False
     self.written = set()
     self.on_ready = None  # callable(param) or None
+    # callable(param) -> True / False / None, asked when a weight gradient has been queued: True = issue the queued group now (the
+    # reducer answers True when the queue holds every outstanding gradient of a bucket and enough bytes for an efficient grouped
+    # launch), None = no opinion (the count-based default below decides)
+    self.on_queued = None
     # Weight gradients of bias-free Linears have no consumer inside backward, so they are queued and issued several at a
     # time as ONE grouped launch (ops.gemm_tn_grouped): whole-K tiles for the full rounds of the persistent grid, split-K only
     # for the remainder.  The more problems per launch the smaller that remainder (one block = 108 tiles is all remainder:
@@ -48,17 +52,33 @@ class GradSink:
 
   def defer_dw(self, dy, x, p):
     """Queue dW(p) (+)= dy^T x; runs when the group is full or at flush_dw()."""
-    self.dw_queue.append((dy, x, p, not self.first_write(p)))
     if isinstance(dy, torch.Tensor) and isinstance(x, torch.Tensor):
-      self.dw_queue_bytes += dy.numel() * dy.element_size() + x.numel() * x.element_size()
+      nbytes = dy.numel() * dy.element_size() + x.numel() * x.element_size()
       if self.dw_queue_bytes_max is None:
-        import os
-        gb = os.environ.get('PLM_DW_QUEUE_GB')
-        self.dw_queue_bytes_max = (int(float(gb) * 2 ** 30) if gb else
-                                   torch.cuda.get_device_properties(dy.device).total_memory // 4 if dy.is_cuda else 1 << 62)
-    if (len(self.dw_queue) >= (self.dw_group_ddp if self.on_ready is not None else self.dw_group_local)
-        or (self.dw_queue_bytes_max is not None and self.dw_queue_bytes > self.dw_queue_bytes_max)):
+        self.resolve_queue_budget(dy.device)
+      if self.dw_queue and self.dw_queue_bytes + nbytes > self.dw_queue_bytes_max:
+        self._flush_linear_dw()  # BEFORE the append: the queue never pins more than the budget
+      self.dw_queue_bytes += nbytes
+    self.dw_queue.append((dy, x, p, not self.first_write(p)))
+    verdict = self.on_queued(p) if self.on_queued is not None else None
+    if verdict is None:
+      verdict = len(self.dw_queue) >= (self.dw_group_ddp if self.on_ready is not None else self.dw_group_local)
+    if verdict or len(self.dw_queue) >= self.dw_group_local:
       self._flush_linear_dw()
+
+  def resolve_queue_budget(self, device, agreed=None):
+    """Byte budget of the dW queue, resolved ONCE (not on the backward path): PLM_DW_QUEUE_GB, else a quarter of the device's
+    memory; data-parallel runs pass the minimum over the ranks (`agreed`, ddp.agree_min) - ranks that flush at different points
+    would launch their gradient buckets in different orders."""
+    if agreed is not None:
+      self.dw_queue_bytes_max = int(agreed)
+      return self.dw_queue_bytes_max
+    import os
+    gb = os.environ.get('PLM_DW_QUEUE_GB')
+    dev = torch.device(device)
+    self.dw_queue_bytes_max = (int(float(gb) * 2 ** 30) if gb else
+                               torch.cuda.get_device_properties(dev).total_memory // 4 if dev.type == 'cuda' else 1 << 62)
+    return self.dw_queue_bytes_max
 
   def defer_norm_dw(self, part, p):
     self.norm_queue.append((part, p, not self.first_write(p)))

@@ -22,6 +22,9 @@ def _stream():
 # Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, every MFMA
 # kernel launch is bracketed by HIP events on the launch stream and (family, flops, start, end) appended.
 PROFILE = None
+# Called with (family, flops) right before every MFMA kernel launch when set (ddp.GradReducer: it keeps an estimate of the GPU time
+# enqueued so far and reserves CUs for RCCL only while a gradient bucket's collective is expected to be running).
+LAUNCH_HOOK = None
 
 
 class _Timed:
@@ -42,6 +45,13 @@ class _Timed:
       end.record()
       PROFILE.append((self.family, self.flops, self.start, end))
     return False
+
+
+def _hook(family, flops):
+  """First thing in every MFMA op, BEFORE its workspace query: the hook may change the CU reserve, and plans (tile shape, stream-K /
+  split-K workspace) are functions of it."""
+  if LAUNCH_HOOK is not None:
+    LAUNCH_HOOK(family, flops)
 
 
 def _p(t):
@@ -283,6 +293,7 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, varian
   if alpha is not None:
     _need(alpha, F32, 'gemm_nt.alpha')
   lib = _lib.load()
+  _hook('gemm_nt', 2.0 * M * N * K)
   nbytes = _nt_ws_bytes(lib, M, N, K) if (variant == 0 and cd == 0) else 0
   ws = _tn_workspace(nbytes, A.device) if nbytes else None  # the split-K slab buffer is shared with gemm_tn (same stream)
   with _Timed('gemm_nt', 2.0 * M * N * K):
@@ -306,6 +317,7 @@ def gemm_tn(A, B, out=None, accumulate=False, alpha=None):
   if out.dtype != F32 or out.shape != (M, N) or out.stride(1) != 1:
     raise ValueError('gemm_tn.out: need fp32 [M, N] with unit inner stride')
   lib = _lib.load()
+  _hook('gemm_tn', 2.0 * M * N * K)
   nbytes = lib.plm_gemm_tn_workspace_bytes(M, N, K)
   ws = _tn_workspace(nbytes, A.device) if nbytes else None
   if alpha is not None:
@@ -344,11 +356,12 @@ def gemm_tn_grouped(problems):
     Ms[i], Ns[i] = M, N
     arr[i] = _lib.TnProblem(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, int(bool(accumulate)), _p(alpha))
   lib = _lib.load()
+  flops = sum(2.0 * a.shape[1] * b.shape[1] * K for a, b, *_ in problems)
+  _hook('gemm_tn', flops)
   nbytes = lib.plm_gemm_tn_grouped_workspace_bytes(Ms, Ns, n, K)
   if nbytes == 0:
     return False
   ws = _tn_workspace(nbytes, problems[0][0].device)
-  flops = sum(2.0 * a.shape[1] * b.shape[1] * K for a, b, *_ in problems)
   with _Timed('gemm_tn', flops):
     _lib.check(lib.plm_gemm_bf16_tn_grouped(arr, n, K, _p(ws), nbytes, _stream()), 'plm_gemm_bf16_tn_grouped')
   return True
@@ -365,6 +378,7 @@ def fc1_swiglu(x, w_fc1):
   h = N // 2
   u = torch.empty((M, N), dtype=BF16, device=x.device)
   act = torch.empty((M, h), dtype=BF16, device=x.device)
+  _hook('gemm_nt_fused', 2.0 * M * N * K)
   with _Timed('gemm_nt_fused', 2.0 * M * N * K):
     _lib.check(_lib.load().plm_fc1_swiglu_bf16(_p(x), x.stride(0), _p(w_fc1), w_fc1.stride(0), _p(u), _p(act), M, h, K, _stream()),
                'plm_fc1_swiglu_bf16')
@@ -383,6 +397,7 @@ def fc2_dx_swiglu_bwd(dy, w2t, u):
     raise ValueError('fc2_dx_swiglu_bwd: need dy [M, K], w2t [h, K], contiguous u [M, 2h]')
   du = torch.empty((M, 2 * h), dtype=BF16, device=dy.device)
   lib = _lib.load()
+  _hook('gemm_nt_fused', 2.0 * M * h * K)
   with _Timed('gemm_nt_fused', 2.0 * M * h * K):
     # first without the d(act) scratch: the one-launch path never touches it; the library answers PLM_E_WORKSPACE (-4) when this
     # shape takes the two-launch path, and only then is the buffer allocated
@@ -416,6 +431,7 @@ def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
   N = w_qkv.shape[0]
   hd = N // (3 * nh)
   out = torch.empty((M, N), dtype=BF16, device=x.device)
+  _hook('gemm_nt_fused', 2.0 * M * N * K)
   with _Timed('gemm_nt_fused', 2.0 * M * N * K):
     _lib.check(_lib.load().plm_qkv_rope_bf16(_p(x), x.stride(0), _p(w_qkv), w_qkv.stride(0), _p(out), N, M, K, _p(rope_cos),
                                              _p(rope_sin), B, T, nh, hd, _stream()), 'plm_qkv_rope_bf16')
@@ -430,6 +446,7 @@ def attn_fwd(qkv_rot, B, T, nh, doc_start=None):
     _need(doc_start, torch.int32, 'attn_fwd.doc_start', 2)
   out = torch.empty((B * T, nh * hd), dtype=BF16, device=qkv_rot.device)
   lse = torch.empty((B, nh, T), dtype=F32, device=qkv_rot.device)
+  _hook('attn_fwd', 4.0 * B * nh * hd * T * (T + 1) / 2)
   with _Timed('attn_fwd', 4.0 * B * nh * hd * T * (T + 1) / 2):
     _lib.check(_lib.load().plm_attn_fwd(_p(qkv_rot), _p(doc_start), _p(out), _p(lse), B, T, nh, hd, _stream()), 'plm_attn_fwd')
   return out, lse
@@ -440,6 +457,7 @@ def attn_bwd(qkv, out, dout, lse, rope_cos, rope_sin, B, T, nh, doc_start=None):
   hd = qkv.shape[1] // (3 * nh)
   dqkv = torch.empty_like(qkv)
   delta = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
+  _hook('attn_bwd', 8.0 * B * nh * hd * T * (T + 1) / 2)
   with _Timed('attn_bwd', 8.0 * B * nh * hd * T * (T + 1) / 2):
     _lib.check(_lib.load().plm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(rope_cos), _p(rope_sin), _p(doc_start),
                                         _p(dqkv), _p(delta), B, T, nh, hd, _stream()), 'plm_attn_bwd')

@@ -273,6 +273,12 @@ class Transformer(nn.Module):
         n[id(m.weight)] = n.get(id(m.weight), 0) + 1
     return n
 
+  def grad_groups(self):
+    """Parameter indices (parameters() order) of every block's Linear weights: their gradients leave ONE grouped dW launch together,
+    so ddp.plan_buckets keeps each list inside one bucket when it fits."""
+    index = {id(p): i for i, p in enumerate(self.parameters())}
+    return [[index[id(m.weight)] for m in layer.modules() if isinstance(m, HipLinear)] for layer in self.layers]
+
   def attach_grads(self):
     """Expose the flat buffer through ``p.grad`` for optimizers / clipping."""
     self.sink.flush_dw()

@@ -251,6 +251,58 @@ def test_gradsink_groups_weight_gradient_gemms(monkeypatch):
   sink.begin_window()
   for p in params:
     sink.defer_dw(torch.zeros(100), torch.zeros(100), p)
-  assert [len(c) for c in calls] == [4] and sink.dw_queue_bytes == 800  # issued when the 4th pair crossed the budget; one pair left
+  assert [len(c) for c in calls] == [3] and sink.dw_queue_bytes == 1600  # issued BEFORE the 4th pair would have crossed the budget; two pairs left
   sink.flush_dw()
-  assert calls[1] == ('single', False) and sink.dw_queue_bytes == 0
+  assert len(calls[1]) == 2 and sink.dw_queue_bytes == 0
+
+
+def test_buckets_keep_blocks_whole_and_dw_groups_end_at_bucket_boundaries():
+  """Round 4: with the blocks' Linear weights declared as groups, no block straddles two buckets (its four
+  gradients leave one grouped dW launch together), and the reducer tells the dW queue to launch exactly at bucket boundaries once
+  the queue holds PLM_DW_GROUP_MB of gradients: 160M, 64 MiB buckets = two blocks each, groups of four blocks = two buckets."""
+  import torch
+  from plainlm_amd import ddp
+  d, h, V, L = 768, 2048, 50280, 12
+  sizes = [d] * (2 * L + 1) + [V * d] + [3 * d * d, d * d, 2 * h * d, d * h] * L + [V * d]
+  spans, off = [], 0
+  for n in sizes:
+    spans.append((off, n))
+    off += n
+  first = 2 * L + 2
+  groups = [list(range(first + 4 * l, first + 4 * l + 4)) for l in range(L)]
+  b = ddp.plan_buckets(spans, cap_bytes=64 << 20, groups=groups)
+  assert b[0][2] == [len(sizes) - 1] and b[-1][2] == list(range(2 * L + 2))
+  for _, _, idxs in b[1:-1]:
+    assert len(idxs) == 8 and idxs[0] == groups[(idxs[0] - first) // 4][0]  # two whole blocks
+  assert sum(hi - lo for lo, hi, _ in b) == off
+  # without the groups the same cap cuts through blocks
+  assert any(len(idxs) % 4 for _, _, idxs in ddp.plan_buckets(spans, cap_bytes=64 << 20)[1:-1])
+
+  class FakeComm:
+    world_size, backend = 2, 'fake'
+    def allreduce_avg_(self, span, stream=None):
+      pass
+  flat = torch.zeros(8)  # CPU: nothing is launched on a device; the spans only need to be consistent
+  params = [object() for _ in sizes]
+  red = ddp.GradReducer(flat, params, spans, FakeComm(), bucket_cap_mb=64, groups=groups)
+  assert red.dw_group_bytes == 80_000_000
+  red.begin(sync=True)
+  launched = []
+  red._launch = lambda bkt, tail=False: launched.append(bkt)
+  red.overlap = True  # (CPU reducers launch everything in finish(); here the launch order is what is being checked)
+  red.param_ready(params[-1])  # lm_head
+  assert launched == [0]
+  verdicts = []
+  for l in range(L - 1, -1, -1):  # backward: block by block from the top, fc2 / fc1 / w_out / w_qkv inside a block
+    for j in (3, 2, 1, 0):
+      i = first + 4 * l + j
+      v = red.param_queued(params[i])
+      verdicts.append(bool(v))
+      if v:  # the sink launches the group and reports every member
+        for q in sorted(red._queued, reverse=True):
+          red.param_ready(params[q])
+  # a launch after every FOURTH block (113 MB >= 80 MB, at a bucket boundary; two blocks = 57 MB is a boundary but too small)
+  assert [k for k, v in enumerate(verdicts) if v] == [15, 31, 47]
+  assert launched == [0, 1, 2, 3, 4, 5, 6]
+  red.begin(sync=False)
+  assert red.param_queued(params[first]) is None  # micro-steps that do not communicate: the sink's own count decides

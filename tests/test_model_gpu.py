@@ -551,17 +551,41 @@ def test_rccl_reducer_single_rank(P, mdl):
   fired = []
   orig = comm.allreduce_avg_
   comm.allreduce_avg_ = lambda span, stream: (fired.append(span.numel()), orig(span, stream))[1]
-  m.sink.begin_window()
-  red.begin(sync=True)
-  m.loss(ids, tgt).backward()
-  n_during_backward = len(fired)
-  assert ops.cu_reserve() == 16  # CUs are set aside from the first bucket launch ...
-  red.finish()
-  assert ops.cu_reserve() == 0   # ... until the streams are joined
-  torch.cuda.synchronize()
-  assert n_during_backward == len(red.buckets) == len(fired)  # every bucket launched from inside backward
-  assert sum(fired) == m._flat_grad.numel()
-  assert torch.equal(m._flat_grad, want)  # every gradient kernel is deterministic (the embedding backward is sort-based)
+  # CUs are set aside for GEMMs that are expected to run beside a collective: a window of estimated GPU time behind every bucket
+  # launch.  Pinned here to "a collective takes a second" (every GEMM enqueued after the first bucket launch is inside a window) ...
+  red.model_gbps, red.bucket_secs = 1e-9, [1.0] * len(red.buckets)
+  seen = []
+  real_set = ops.set_cu_reserve
+  ops.set_cu_reserve = lambda n: (seen.append(n), real_set(n))[1]
+  try:
+    m.sink.begin_window()
+    red.begin(sync=True)
+    assert ops.LAUNCH_HOOK is not None
+    m.loss(ids, tgt).backward()
+    n_during_backward = len(fired)
+    assert ops.cu_reserve() == 16 and seen == [16]  # ... from the first GEMM behind the first bucket launch ...
+    red.finish()
+    assert ops.cu_reserve() == 0 and ops.LAUNCH_HOOK is None  # ... until the streams are joined
+    torch.cuda.synchronize()
+    assert n_during_backward == len(red.buckets) == len(fired)  # every bucket launched from inside backward
+    assert sum(fired) == m._flat_grad.numel()
+    assert torch.equal(m._flat_grad, want)  # every gradient kernel is deterministic (the embedding backward is sort-based)
+    # ... and to "a collective takes no time": no GEMM is ever inside a window, the grids never shrink
+    red.bucket_secs = [0.0] * len(red.buckets)
+    seen.clear()
+    m.sink.begin_window()
+    red.begin(sync=True)
+    m.loss(ids, tgt).backward()
+    red.finish()
+    torch.cuda.synchronize()
+    assert seen == [] and ops.cu_reserve() == 0 and torch.equal(m._flat_grad, want)
+    # measured durations: with the model switched off, begin() folds the previous step's collectives into the estimate
+    red.model_gbps = None
+    red.begin(sync=True)
+    assert all(0.0 < s < 0.05 for s in red.bucket_secs)  # half of zero + half of a few microseconds of 1-rank copies
+    red.finish()
+  finally:
+    ops.set_cu_reserve = real_set
   comm.close()
 
 
