@@ -89,9 +89,12 @@ __device__ __forceinline__ void st_bf16x8(uint16_t* p, bf16x8_t v) { *reinterpre
 #endif
 __device__ __forceinline__ void st_c_bf16x8(uint16_t* p, bf16x8_t v) {
 #if PLM_C_STORE_MODE == 1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  // an asm dwordx4 store ends with s_nop 1 INSIDE the string: hipcc pads nothing around an asm statement, and its next instruction
+  // may overwrite the data registers before the store has read them (cdna_hip_programming.md section 5.7; the first build of the nt
+  // variant lacked it and stored garbage in the 256x192 kernel - caught by test_gemm_nt_variants)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #elif PLM_C_STORE_MODE == 2
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x8_t*>(p));  // global_store_dwordx4 ... nt, counted and padded by hipcc
 #else
   *reinterpret_cast<bf16x8_t*>(p) = v;
 #endif
