@@ -292,12 +292,13 @@ def main():
   pool = [(tok[i * B:(i + 1) * B, :T].contiguous().to(device), tok[i * B:(i + 1) * B, 1:].contiguous().to(device),
            doc_starts(B) if a.doc_mask else None) for i in range(n_pool)]
 
-  def fwd_bwd(i):
+  def fwd_bwd(i, recast=True):
     ids, tgt, dstart = pool[i % n_pool]
     model.sink.begin_window()
     if reducer is not None:
       reducer.begin(sync=True)
-    model.invalidate_shadows()  # a real step changes the weights: redo the bf16 casts every step like autocast
+    if recast:
+      model.invalidate_shadows()  # a real step changes the weights: redo the bf16 casts every step like autocast
     loss = model.loss(ids, tgt, dstart)
     loss.backward()
     if reducer is not None:
@@ -393,7 +394,7 @@ def main():
         model.sink.on_queued = reducer.param_queued
 
       def full(i):
-        fwd_bwd(i)
+        fwd_bwd(i, recast=not opt.emits_shadows)  # FlatAdamW writes the bf16 shadows of the weights it has just updated
         opt.clip_and_step(1.0)
 
       for i in range(2):
@@ -406,7 +407,10 @@ def main():
       torch.cuda.synchronize()
       full_ms = 1e3 * (time.perf_counter() - t1) / nfull
       out['full_step'] = {'ms_per_step': round(full_ms, 3), 'tokens_per_sec_per_gpu': round(B * T / full_ms * 1e3, 1),
-                          'note': 'fwd+bwd + global-norm clip + AdamW (plainlm_amd FlatAdamW kernels; rank-local clock, untimed leg)'}
+                          'over_fwd_bwd_ms': round(full_ms - ms_per_step, 3),
+                          'note': 'fwd+bwd + global-norm clip + AdamW (plainlm_amd FlatAdamW kernels; rank-local clock, untimed leg)'
+                                  + ('; the AdamW launch also emits the bf16 weight shadows, so this leg has no stand-alone weight cast'
+                                     if opt.emits_shadows else '')}
 
     if world == 1:
       out['cpu_baseline'] = cpu_baseline(c)

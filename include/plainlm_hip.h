@@ -32,7 +32,8 @@ extern "C" {
 
 int plm_version(void);
 const char* plm_last_error_string(void);
-/* The library reads its environment switches (PLM_GEMM_V1, PLM_TN_NO_BIG, PLM_NT_NO_HYBRID, PLM_NT_HYBRID_MIN_K: tests and A/B
+/* The library reads its environment switches (PLM_GEMM_V1, PLM_TN_NO_BIG, PLM_NT_NO_HYBRID, PLM_NT_HYBRID_MIN_K, PLM_NT_DUO,
+ * PLM_DUO_STAGGER_US, PLM_DUO_DBG: tests and A/B
  * runs; none is needed in production) ONCE, at its first call - no launch path calls getenv.  A process that changes one of them
  * afterwards (the test-suite does) calls this to have them read again. */
 void plm_reload_env(void);
@@ -211,6 +212,21 @@ int plm_axpy_f32(float* out, const float* x, int64_t n, const float* alpha_dev, 
 int plm_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, void* stream);
 int plm_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float bc1, float bc2, const float* clip_coef_dev, void* stream);
+/* The same update for a list of Linear weights [rows, cols] that ALSO writes the bf16 shadows the next step's GEMMs read
+ * (dst = bf16(W) [rows, cols], dst_t = bf16(W)^T [cols, ld_t], columns 0..rows-1), i.e. plm_adamw_f32 followed by
+ * plm_cast_f32_bf16_t_multi in one pass over the parameters ("bf16 weight shadow copy emitted by the
+ * optimizer"; replaces the per-call fp32 -> bf16 weight casts of autocast, engine/engine.py:75).  Same bits as the two calls. */
+typedef struct plm_adamw_item {
+  float* p;         /* fp32 [rows, cols], updated in place */
+  const float* g;   /* fp32 gradient */
+  float* m;         /* exp_avg */
+  float* v;         /* exp_avg_sq */
+  uint16_t* dst;    /* bf16 [rows, cols] */
+  uint16_t* dst_t;  /* bf16 [cols, ld_t] */
+  int64_t rows, cols, ld_t;
+} plm_adamw_item;
+int plm_adamw_cast_multi(const plm_adamw_item* items, int count, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float bc1, float bc2, const float* clip_coef_dev, void* stream);
 
 /* Leave `n` CUs free when sizing the persistent GEMM grids (one workgroup per CU, static tile schedule), so that
  * concurrently running RCCL collectives do not push GEMM workgroups into a second round.  Process-wide; 0 = whole chip. */

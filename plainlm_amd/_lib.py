@@ -17,7 +17,7 @@ _lib = None
 
 # ABI the signatures below were written for (plm_version() of the library must match: a stale .so that still exports every
 # symbol but with other argument lists / struct layouts would corrupt memory instead of raising)
-EXPECTED_ABI = 104
+EXPECTED_ABI = 105
 
 _P = C.c_void_p
 _I64 = C.c_int64
@@ -28,6 +28,11 @@ _SZ = C.c_size_t
 class CastItem(C.Structure):
   """struct plm_cast_item (include/plainlm_hip.h)."""
   _fields_ = [('src', _P), ('dst', _P), ('dst_t', _P), ('rows', _I64), ('cols', _I64), ('ld_t', _I64)]
+
+
+class AdamwItem(C.Structure):
+  """struct plm_adamw_item (include/plainlm_hip.h)."""
+  _fields_ = [('p', _P), ('g', _P), ('m', _P), ('v', _P), ('dst', _P), ('dst_t', _P), ('rows', _I64), ('cols', _I64), ('ld_t', _I64)]
 
 
 class ColsumItem(C.Structure):
@@ -80,6 +85,7 @@ SIGNATURES = {
   'plm_axpy_f32': (_I, [_P, _P, _I64, _P, _I, _P]),
   'plm_sumsq_f32': (_I, [_P, _I64, _P, _P, _P]),
   'plm_adamw_f32': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+  'plm_adamw_cast_multi': (_I, [C.POINTER(AdamwItem), _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
   'plm_set_cu_reserve': (_I, [_I]),
   'plm_comm_unique_id': (_I, [_P]),
   'plm_comm_init': (_I, [C.POINTER(_P), _P, _I, _I, _I]),

@@ -819,6 +819,19 @@ extern "C" int plm_sumsq_f32(const float* x, int64_t n, float* scratch, float* o
 // ===========================================================================
 // AdamW on a flat fp32 span  (torch.optim.AdamW semantics; optim/init_optim.py:14-21)
 // ===========================================================================
+// One element of torch.optim.AdamW (decoupled decay; bias corrections folded into step / bc2_sqrt), with every rounding spelled out so that
+// the flat kernel and the shadow-emitting one produce the same bits whatever the compiler would contract around them.
+__device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& v, float cs, float b1, float b2, float eps, float decay, float step,
+                                            float bc2_sqrt) {
+  const float gi = __fmul_rn(g, cs);
+  const float mi = __fmaf_rn(b1, m, __fmul_rn(1.f - b1, gi));
+  const float vi = __fmaf_rn(b2, v, __fmul_rn(__fmul_rn(1.f - b2, gi), gi));
+  m = mi;
+  v = vi;
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+  return __fmaf_rn(-step, __fdiv_rn(mi, denom), __fmul_rn(p, decay));
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
@@ -826,15 +839,140 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float step = lr / bc1;
   const float decay = 1.f - lr * wd;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i] * cs;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 bytes per lane and array where the span allows it (every span FlatAdamW passes starts on a 16-byte boundary; a ragged tail
+  // and misaligned callers take the scalar loop)
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  for (int64_t i = tid; i < n4; i += stride) {
+    f32x4_t pv = *reinterpret_cast<const f32x4_t*>(p + 4 * i);
+    const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + 4 * i);
+    f32x4_t mv = *reinterpret_cast<const f32x4_t*>(m + 4 * i), vv = *reinterpret_cast<const f32x4_t*>(v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float me = mv[e], ve = vv[e];
+      pv[e] = adamw_elem(pv[e], gv[e], me, ve, cs, b1, b2, eps, decay, step, bc2_sqrt);
+      mv[e] = me;
+      vv[e] = ve;
+    }
+    *reinterpret_cast<f32x4_t*>(m + 4 * i) = mv;
+    *reinterpret_cast<f32x4_t*>(v + 4 * i) = vv;
+    *reinterpret_cast<f32x4_t*>(p + 4 * i) = pv;
+  }
+  for (int64_t i = 4 * n4 + tid; i < n; i += stride) {
+    float mi = m[i], vi = v[i];
+    p[i] = adamw_elem(p[i], g[i], mi, vi, cs, b1, b2, eps, decay, step, bc2_sqrt);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] * decay - step * (mi / denom);
   }
+}
+
+// AdamW for a list of Linear weights that also emits the bf16 shadows the next forward / backward consume (W [rows, cols] and
+// W^T [cols, ld_t]): the arithmetic of adamw_kernel per element, the tile walk and LDS transposition of
+// cast_f32_bf16_t_multi_kernel.  One read of p / g / m / v, one write of p / m / v, plus 4 bytes per parameter of shadows - the
+// stand-alone cast (one more read of p, the same shadow writes) disappears from the training step.
+#define PLM_ADAMW_MULTI_MAX 56
+struct AdamwGroup {
+  float* p[PLM_ADAMW_MULTI_MAX];
+  const float* g[PLM_ADAMW_MULTI_MAX];
+  float* m[PLM_ADAMW_MULTI_MAX];
+  float* v[PLM_ADAMW_MULTI_MAX];
+  uint16_t* dst[PLM_ADAMW_MULTI_MAX];
+  uint16_t* dst_t[PLM_ADAMW_MULTI_MAX];
+  int rows[PLM_ADAMW_MULTI_MAX], cols[PLM_ADAMW_MULTI_MAX], ld_t[PLM_ADAMW_MULTI_MAX];
+  int block_base[PLM_ADAMW_MULTI_MAX + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void adamw_cast_multi_kernel(AdamwGroup g, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                               float bc2_sqrt, const float* __restrict__ clip) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+  int it = 0;
+  for (int q = 1; q < g.count; ++q)
+    if ((int)blockIdx.x >= g.block_base[q]) it = q;  // block-uniform scalar search
+  const int local = blockIdx.x - g.block_base[it];
+  const int tiles_x = (g.cols[it] + 63) / 64;
+  const int64_t rows = g.rows[it], cols = g.cols[it], ld_t = g.ld_t[it];
+  float* __restrict__ P = g.p[it];
+  const float* __restrict__ G = g.g[it];
+  float* __restrict__ Mm = g.m[it];
+  float* __restrict__ V = g.v[it];
+  uint16_t* __restrict__ dst = g.dst[it];
+  uint16_t* __restrict__ dst_t = g.dst_t[it];
+  const int64_t r0 = (int64_t)(local / tiles_x) * 64, c0 = (int64_t)(local % tiles_x) * 64;
+  const float cs = clip ? *clip : 1.f;
+  const float step = lr / bc1;
+  const float decay = 1.f - lr * wd;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+    const int64_t gr = r0 + r, gc = c0 + c;
+    const bool in = gr < rows && gc < cols;  // cols % 8 == 0: the four columns are in range together
+    f32x4_t pn = {0.f, 0.f, 0.f, 0.f};
+    if (in) {
+      const int64_t o = gr * cols + gc;
+      const f32x4_t pv = *reinterpret_cast<const f32x4_t*>(P + o), gv = *reinterpret_cast<const f32x4_t*>(G + o);
+      f32x4_t mv = *reinterpret_cast<const f32x4_t*>(Mm + o), vv = *reinterpret_cast<const f32x4_t*>(V + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float me = mv[e], ve = vv[e];
+        pn[e] = adamw_elem(pv[e], gv[e], me, ve, cs, b1, b2, eps, decay, step, bc2_sqrt);
+        mv[e] = me;
+        vv[e] = ve;
+      }
+      *reinterpret_cast<f32x4_t*>(Mm + o) = mv;
+      *reinterpret_cast<f32x4_t*>(V + o) = vv;
+      *reinterpret_cast<f32x4_t*>(P + o) = pn;
+    }
+    bf16x4_t o4;
+    o4[0] = f2bf(pn[0]); o4[1] = f2bf(pn[1]); o4[2] = f2bf(pn[2]); o4[3] = f2bf(pn[3]);
+    if (in) st_bf16x4(dst + gr * cols + gc, o4);
+    tile[c + 0][r] = o4[0]; tile[c + 1][r] = o4[1]; tile[c + 2][r] = o4[2]; tile[c + 3][r] = o4[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (t >> 3) + 32 * i, rch = (t & 7) * 8;
+    const int64_t gc = c0 + c, gr = r0 + rch;
+    if (gc < cols && gr < rows) {
+      const bf16x8_t v8 = *reinterpret_cast<const bf16x8_t*>(&tile[c][rch]);
+      st_bf16x8(dst_t + gc * ld_t + gr, v8);
+    }
+  }
+}
+
+extern "C" int plm_adamw_cast_multi(const plm_adamw_item* items, int count, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, float bc1, float bc2, const float* clip_coef_dev, void* stream) {
+  PLM_REQUIRE(items && count >= 1, "plm_adamw_cast_multi: null pointer or empty list");
+  for (int first = 0; first < count; first += PLM_ADAMW_MULTI_MAX) {
+    const int n = count - first < PLM_ADAMW_MULTI_MAX ? count - first : PLM_ADAMW_MULTI_MAX;
+    AdamwGroup g{};
+    int base = 0;
+    for (int i = 0; i < n; ++i) {
+      const plm_adamw_item& q = items[first + i];
+      PLM_REQUIRE(q.p && q.g && q.m && q.v && q.dst && q.dst_t, "plm_adamw_cast_multi: null pointer in item %d", first + i);
+      PLM_REQUIRE(q.rows > 0 && q.cols > 0 && q.rows % 8 == 0 && q.cols % 8 == 0 && q.rows < (1ll << 31) && q.cols < (1ll << 31),
+                  "plm_adamw_cast_multi: item %d: rows=%ld cols=%ld must be positive multiples of 8", first + i, (long)q.rows, (long)q.cols);
+      PLM_REQUIRE(q.ld_t >= q.rows && q.ld_t % 8 == 0 && q.ld_t < (1ll << 31), "plm_adamw_cast_multi: item %d: ld_t=%ld must be >= rows and a multiple of 8",
+                  first + i, (long)q.ld_t);
+      PLM_REQUIRE(((reinterpret_cast<uintptr_t>(q.p) | reinterpret_cast<uintptr_t>(q.g) | reinterpret_cast<uintptr_t>(q.m) | reinterpret_cast<uintptr_t>(q.v) |
+                    reinterpret_cast<uintptr_t>(q.dst) | reinterpret_cast<uintptr_t>(q.dst_t)) & 15) == 0,
+                  "plm_adamw_cast_multi: item %d: pointers must be 16-byte aligned", first + i);
+      g.p[i] = q.p; g.g[i] = q.g; g.m[i] = q.m; g.v[i] = q.v; g.dst[i] = q.dst; g.dst_t[i] = q.dst_t;
+      g.rows[i] = (int)q.rows; g.cols[i] = (int)q.cols; g.ld_t[i] = (int)q.ld_t;
+      g.block_base[i] = base;
+      const int64_t nb = plm_cdiv(q.rows, 64) * plm_cdiv(q.cols, 64);
+      PLM_REQUIRE(base + nb < (1ll << 31), "plm_adamw_cast_multi: too many tiles");
+      base += (int)nb;
+    }
+    g.block_base[n] = base;
+    g.count = n;
+    hipLaunchKernelGGL(adamw_cast_multi_kernel, dim3((unsigned)base), dim3(256), 0, (hipStream_t)stream, g, lr, beta1, beta2, eps, weight_decay, bc1,
+                       sqrtf(bc2), clip_coef_dev);
+    PLM_CHECK_LAUNCH("plm_adamw_cast_multi");
+  }
+  return PLM_OK;
 }
 
 extern "C" int plm_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

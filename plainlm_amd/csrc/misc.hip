@@ -15,7 +15,7 @@ void plm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* plm_last_error_string(void) { return g_err; }
-extern "C" int plm_version(void) { return 104; }  // 104: round 3 (+ plm_reload_env); 103 / 102: round 2 (see include/plainlm_hip.h); 101: round 1
+extern "C" int plm_version(void) { return 105; }  // 105: round 4 (+ plm_adamw_cast_multi, NT variant 7, PLM_NT_DUO / PLM_DUO_* switches); 104: round 3 (+ plm_reload_env); 103 / 102: round 2 (see include/plainlm_hip.h); 101: round 1
 
 static PlmEnv g_env;
 static void load_env() {

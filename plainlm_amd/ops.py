@@ -523,6 +523,27 @@ def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None
                                        _p(clip_coef), _stream()), 'plm_adamw_f32')
 
 
+def adamw_cast_multi_(items, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None, table=None):
+  """AdamW on a list of Linear weights that also writes their bf16 shadows: items = [(p, g, m, v fp32 [rows, cols], dst bf16 [rows, cols],
+  dst_t bf16 [cols, >= rows])].  Returns the ctypes item table; pass it back as `table` on later steps (the pointers do not move)."""
+  if table is None:
+    table = (_lib.AdamwItem * len(items))()
+    for i, (p, g, m, v, dst, dst_t) in enumerate(items):
+      for t, n in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _need(t, F32, 'adamw_cast_multi.' + n, 2)
+      R, Cc = p.shape
+      if dst.dtype != BF16 or tuple(dst.shape) != (R, Cc) or not dst.is_contiguous() or not dst.is_cuda:
+        raise ValueError('adamw_cast_multi.dst: need contiguous bf16 [rows, cols] on the GPU')
+      if dst_t.dtype != BF16 or dst_t.dim() != 2 or dst_t.shape[0] != Cc or dst_t.shape[1] < R or dst_t.stride(1) != 1 or not dst_t.is_cuda:
+        raise ValueError('adamw_cast_multi.dst_t: need bf16 [cols, >= rows] on the GPU')
+      table[i] = _lib.AdamwItem(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), dst.data_ptr(), dst_t.data_ptr(), R, Cc, dst_t.stride(0))
+  bc1 = 1.0 - beta1 ** step
+  bc2 = 1.0 - beta2 ** step
+  _lib.check(_lib.load().plm_adamw_cast_multi(table, len(table), lr, beta1, beta2, eps, weight_decay, bc1, bc2, _p(clip_coef), _stream()),
+             'plm_adamw_cast_multi')
+  return table
+
+
 # ---- probes -------------------------------------------------------------------------------
 def probe_ds_read_tr16():
   out = torch.empty(256, dtype=torch.int32, device='cuda')

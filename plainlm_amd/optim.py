@@ -65,6 +65,35 @@ class FlatAdamW(torch.optim.AdamW):
     self._step_count = 0
     self.last_grad_norm = None
     self._publish_state()
+    # SURVEY section 8f N1, second half: the Linear weights' update also writes their bf16 shadows (W and W^T), so the training step has
+    # no stand-alone weight cast (what autocast does per forward, engine/engine.py:75).  Per weight-decay group: the Linear weights
+    # of the group (one fused launch) + the rest of its span (embed_tokens / the norm weights: flat kernel).  PLM_ADAMW_SHADOWS=0
+    # restores the flat kernel for everything + invalidated shadows.
+    import os
+    self.emits_shadows = os.environ.get('PLM_ADAMW_SHADOWS', '1') != '0' and hasattr(model, 'linear_modules')
+    self._fused = [None] * len(self.param_groups)  # per group: (linear modules, item tensors, ctypes table or None, leftover [(lo, hi)])
+    if self.emits_shadows:
+      for gi, g in enumerate(self.param_groups):
+        ids = {id(p) for p in g['params']}
+        lins = [m for m in model.linear_modules() if id(m.weight) in ids]
+        if not lins:
+          continue
+        items, taken = [], []
+        for lin in lins:
+          w = lin.weight
+          lin.stale_item()  # allocates the shadow buffers
+          mview, vview = self._views[id(w)]
+          items.append((w.data, w.main_grad, mview, vview, lin._shadow[0], lin._shadow[1]))
+          taken.append(spans_by_param[id(w)])
+        lo, hi = self.group_spans[gi]
+        rest, cur = [], lo
+        for o, n in sorted(taken):
+          if o > cur:
+            rest.append((cur, o))
+          cur = o + n
+        if cur < hi:
+          rest.append((cur, hi))
+        self._fused[gi] = (lins, items, None, rest)
 
   def _publish_state(self):
     """torch-layout per-parameter state backed by views of the flat moment buffers."""
@@ -83,15 +112,29 @@ class FlatAdamW(torch.optim.AdamW):
       sq = ops.sumsq(self.flat_g, self._scratch)
       self.last_grad_norm = torch.sqrt(sq)
       clip = torch.clamp(float(max_norm) / (self.last_grad_norm + 1e-6), max=1.0).reshape(1).contiguous()
-    for g, (lo, hi) in zip(self.param_groups, self.group_spans):
+    fresh = []
+    for gi, (g, (lo, hi)) in enumerate(zip(self.param_groups, self.group_spans)):
       if hi == lo:
         continue
       b1, b2 = g['betas']
-      ops.adamw_(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], float(g['lr']), b1, b2,
-                 g['eps'], g['weight_decay'], self._step_count, clip)
+      spans = [(lo, hi)]
+      if self._fused[gi] is not None:
+        lins, items, table, spans = self._fused[gi]
+        if any(lin._shadow[0] is not it[4] or lin.weight.data_ptr() != it[0].data_ptr() for lin, it in zip(lins, items)):
+          # a shadow buffer or a weight was re-allocated behind our back (model moved, weights re-laid): rebuild the cached table
+          items = [(lin.weight.data, lin.weight.main_grad) + self._views[id(lin.weight)] + (lin._shadow[0], lin._shadow[1]) for lin in lins]
+          table = None
+        table = ops.adamw_cast_multi_(items, float(g['lr']), b1, b2, g['eps'], g['weight_decay'], self._step_count, clip, table)
+        self._fused[gi] = (lins, items, table, spans)
+        fresh.extend(lins)
+      for a, b in spans:
+        ops.adamw_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], float(g['lr']), b1, b2,
+                   g['eps'], g['weight_decay'], self._step_count, clip)
     for st in self.state.values():
       st['step'].fill_(float(self._step_count))
     self.model.invalidate_shadows()  # raw-pointer update: torch's version counters did not move
+    for lin in fresh:                # ... except where this step has just written the shadows itself
+      lin.mark_fresh()
 
   @torch.no_grad()
   def step(self, closure=None):

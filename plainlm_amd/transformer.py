@@ -285,6 +285,16 @@ class Transformer(nn.Module):
     for p in self.parameters():
       p.grad = p.main_grad
 
+  def linear_modules(self):
+    """The HipLinear modules, one per distinct weight (a weight tied between lm_head and embed_tokens appears once)."""
+    if self._linears is None:
+      seen, self._linears = set(), []
+      for m in self.modules():
+        if isinstance(m, HipLinear) and id(m.weight) not in seen:  # tied weights: one shadow refresh per call site is enough
+          seen.add(id(m.weight))
+          self._linears.append(m)
+    return self._linears
+
   def invalidate_shadows(self):
     for m in self.modules():
       if isinstance(m, HipLinear):
@@ -293,13 +303,7 @@ class Transformer(nn.Module):
   def refresh_shadows(self):
     """Re-cast every stale bf16 weight shadow in ONE launch (the per-Linear casts are launch-latency bound: 49 launches of
     1 - 6 MB at the 160M size).  Called at the top of every forward; HipLinear.shadow() stays as the lazy fallback."""
-    if self._linears is None:
-      seen, self._linears = set(), []
-      for m in self.modules():
-        if isinstance(m, HipLinear) and id(m.weight) not in seen:  # tied weights: one shadow refresh per call site is enough
-          seen.add(id(m.weight))
-          self._linears.append(m)
-    stale = [(m, it) for m in self._linears for it in (m.stale_item(),) if it is not None]
+    stale = [(m, it) for m in self.linear_modules() for it in (m.stale_item(),) if it is not None]
     if not stale or not stale[0][1][0].is_cuda:
       return
     ops.cast_bf16_t_multi([it for _, it in stale])

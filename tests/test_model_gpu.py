@@ -667,6 +667,33 @@ def test_flat_adamw_matches_torch_adamw_and_clip(P, mdl):
     assert abs(opt.last_grad_norm.item() - norm.item()) <= 1e-5 * norm.item()
   for (n, p), q in zip(m.named_parameters(), ref.parameters()):
     assert relmax(p.detach(), q.detach()) < 2e-6, n
+  # N1, second half: the AdamW launch of the Linear weights has written their bf16 shadows - the bits of the stand-alone cast - and
+  # nothing is left to re-cast at the next forward; the flat kernel (PLM_ADAMW_SHADOWS=0) gives the same parameters bit for bit
+  assert opt.emits_shadows
+  lins = m.linear_modules()
+  assert len(lins) == 9  # 4 per block + lm_head
+  for lin in lins:
+    assert lin.stale_item() is None
+    assert torch.equal(lin._shadow[0], lin.weight.detach().bfloat16())
+    assert torch.equal(lin._shadow[1][:, :lin.out_features], lin.weight.detach().bfloat16().t())
+    assert (lin._shadow[1][:, lin.out_features:] == 0).all()
+  m2 = _small(P, mdl, main_grad=True)
+  os.environ['PLM_ADAMW_SHADOWS'] = '0'
+  try:
+    opt2 = FlatAdamW(m2, P.get_param_groups(m2, 0.1), lr=3e-3, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
+  finally:
+    del os.environ['PLM_ADAMW_SHADOWS']
+  assert not opt2.emits_shadows
+  g2 = torch.Generator(device='cuda').manual_seed(0)
+  for step in range(3):
+    for p in m2.parameters():
+      p.main_grad.copy_(torch.randn(p.shape, device='cuda', generator=g2) * (5.0 if step == 0 else 0.01))
+    for grp in opt2.param_groups:
+      grp['lr'] = 3e-3 * (step + 1) / 3
+    opt2.clip_and_step(1.0)
+  for (n, p), p2 in zip(m.named_parameters(), m2.parameters()):
+    assert torch.equal(p.detach(), p2.detach()), n
+  assert all(lin.stale_item() is not None for lin in m2.linear_modules())
   sd = opt.state_dict()
   assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'} and len(sd['state']) == 15
   rsd = ropt.state_dict()
