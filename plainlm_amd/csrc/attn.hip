@@ -553,6 +553,8 @@ extern "C" int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* ro
 extern "C" int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,
                             int64_t hd, void* stream) {
   PLM_REQUIRE(qkv && out && lse, "plm_attn_fwd: null pointer");
+  // LDS-DMA sources and the whole-row epilogue stores (RowStage::flush) are 16-byte accesses
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "plm_attn_fwd: qkv and out must be 16-byte aligned");
   if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
   const dim3 grid((unsigned)(plm_cdiv(T, 128) * nh * B)), block(256);  // see attn_block
   hipStream_t s = (hipStream_t)stream;
@@ -570,6 +572,9 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
                             const float* rope_sin, const int32_t* doc_start, uint16_t* dqkv, float* delta, int64_t B, int64_t T,
                             int64_t nh, int64_t hd, void* stream) {
   PLM_REQUIRE(qkv && out && dout && lse && rope_cos && rope_sin && dqkv && delta, "plm_attn_bwd: null pointer");
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv) |
+                reinterpret_cast<uintptr_t>(rope_cos) | reinterpret_cast<uintptr_t>(rope_sin)) & 15) == 0,
+              "plm_attn_bwd: qkv, out, dout, dqkv and the RoPE tables must be 16-byte aligned");
   if (int rc = check_attn_shape("plm_attn_bwd", B, T, nh, hd)) return rc;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(256);

@@ -37,6 +37,14 @@ __device__ __forceinline__ void attn_block2(int T, int nh, int& tile, int& h, in
   b = bh / nh;
 }
 
+// LDS-DMA instructions one stage() issues per wave: a K | V (or Q | dO) tile pair = 2 x TileDma's two pieces.  The counted waits of the
+// tile loops are multiples of it (the dK/dV kernel's wave 0 adds its two statistics pieces): a stage() that issued a different number, or
+// ANY other vector-memory instruction between a kernel's prologue and its epilogue, would make those waits release tiles that have not
+// landed - nothing else would notice.  Keep the loops free of loads and stores; change this constant with stage().
+constexpr int ATTN_DMA_PER_STAGE = 4;
+constexpr int ATTN_DMA_STATS = 2;  // dK/dV kernel, wave 0: the LSE and delta rows of the query tile
+static_assert(ATTN_DMA_PER_STAGE == 2 * 2, "stage() = two TileDma::issue calls of two instructions each");
+
 #define ATTN_DEFER_LOG2 8.0f  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
 
 enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };  // a 32-row block on a key tile: above its diagonal / no mask needed / masked
@@ -201,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t*
     for (; jt_lo + i < jt_end; ++i) {
       // wait for this wave's pieces of tile i: the tiles issued after it (at most NST - 2, fewer at the end) may stay in flight
       const int rem = min(NST - 2, n - 1 - i);
-      if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
-      else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+      if (NST >= 4 && rem >= 2) attn_wait_vm<2 * ATTN_DMA_PER_STAGE>();
+      else if (NST >= 3 && rem == 1) attn_wait_vm<ATTN_DMA_PER_STAGE>();
       else attn_wait_vm<0>();
       attn_barrier();  // everyone's pieces landed; and every wave is done reading tile i - 1, whose slot is refilled now
       if (i + NST - 1 < n) stage(slot == 0 ? NST - 1 : slot - 1, jt_lo + i + NST - 1);
@@ -376,6 +384,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int db = 0; db < 2; ++db) ktr[db][s2] = frag_cols(sK, db, kb * 32 + s2 * 16 + 4 * hi, lane);
+      // (skipping the key block of a diagonal tile that lies entirely above a row block - one wave-uniform compare - costs this kernel
+      // its last registers: 6 spills; the dK/dV kernel does skip its dead query blocks)
       if (M0 == QB_UM) block(0, kb, kfr, vfr, ktr, kv0, std::false_type{});
       if (M0 == QB_MASK) block(0, kb, kfr, vfr, ktr, kv0, std::true_type{});
       if (M1 == QB_UM) block(1, kb, kfr, vfr, ktr, kv0, std::false_type{});
@@ -390,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
   auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
     for (; jt_lo + i < jt_end; ++i) {
       const int rem = min(NST - 2, n - 1 - i);
-      if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
-      else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+      if (NST >= 4 && rem >= 2) attn_wait_vm<2 * ATTN_DMA_PER_STAGE>();
+      else if (NST >= 3 && rem == 1) attn_wait_vm<ATTN_DMA_PER_STAGE>();
       else attn_wait_vm<0>();
       attn_barrier();
       if (i + NST - 1 < n) stage(slot == 0 ? NST - 1 : slot - 1, jt_lo + i + NST - 1);
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       __builtin_amdgcn_sched_barrier(0);  // one query block's fragments at a time
+      if (MASK && qt0 + qb * 32 + 31 < kvw0) continue;  // every query of the block precedes this wave's first key: P = 0 (wave-uniform)
       bf16x8_t qfr[4], dofr[4], dotr[2][2], qtr[2][2];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -579,14 +590,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
       // wait for this wave's pieces of tile i; the tiles issued after it (at most NST - 2) stay in flight: 4 instructions each, plus
       // the statistics pieces on wave 0
       const int rem = min(NST - 2, n - 1 - i);
-      constexpr int W0 = 6;
+      constexpr int W0 = ATTN_DMA_PER_STAGE + ATTN_DMA_STATS;
       if (wave == 0) {
         if (NST >= 4 && rem >= 2) attn_wait_vm<2 * W0>();
         else if (NST >= 3 && rem == 1) attn_wait_vm<W0>();
         else attn_wait_vm<0>();
       } else {
-        if (NST >= 4 && rem >= 2) attn_wait_vm<8>();
-        else if (NST >= 3 && rem == 1) attn_wait_vm<4>();
+        if (NST >= 4 && rem >= 2) attn_wait_vm<2 * ATTN_DMA_PER_STAGE>();
+        else if (NST >= 3 && rem == 1) attn_wait_vm<ATTN_DMA_PER_STAGE>();
         else attn_wait_vm<0>();
       }
       attn_barrier();

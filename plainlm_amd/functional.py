@@ -257,7 +257,11 @@ class NormFn(torch.autograd.Function):
   """(x, y) = (x, bf16(RMSNorm(x) * w)) for the fp32 x of the first block (the embedding output), which feeds the norm AND the residual
   stream.  x is handed back as a second output (an alias, no copy) so that both of its consumers' gradients arrive HERE: the residual
   path's gradient goes into the norm-backward kernel as its `gin` term - autograd would otherwise sum the two [M, d] fp32 gradients
-  with an elementwise add of its own (the one non-plm kernel round 2's step trace still showed)."""
+  with an elementwise add of its own (the one non-plm kernel round 2's step trace still showed).
+
+  Constraint: the first output is a VIEW of an input created inside a custom Function, so autograd refuses any later in-place
+  operation on it (`x += ...` on block 0's residual stream raises).  The blocks never do that: every residual add is AddNormFn, which
+  writes a new tensor.  tests/test_model_gpu.py::test_normfn_gradient_paths covers the three gradient cases."""
 
   @staticmethod
   def forward(ctx, x, weight, norm):

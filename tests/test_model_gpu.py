@@ -705,3 +705,52 @@ def test_flat_adamw_matches_torch_adamw_and_clip(P, mdl):
   l1 = m.loss(tok[:, :64].cuda(), tok[:, 1:65].cuda()).item()
   l2 = ref.loss(tok[:, :64].cuda(), tok[:, 1:65].cuda()).item()
   assert abs(l1 - l2) <= 1e-4 * abs(l2)
+
+
+def test_normfn_gradient_paths(P):
+  """functional.NormFn hands its fp32 input through as a second output so that the residual path's gradient enters the norm-backward
+  kernel as `gin`: both gradients, only the norm's, only the residual's - each against autograd through the
+  oracle's RMSNorm - and the documented constraint (no in-place operation on the aliased output)."""
+  from plainlm_amd import functional as Fn
+  from plainlm_amd.transformer import RMSNorm
+  g = torch.Generator().manual_seed(3)
+  M, d = 96, 128
+  x0 = torch.randn(M, d, generator=g)
+  w0 = 1 + 0.1 * torch.randn(d, generator=g)
+  gx = torch.randn(M, d, generator=g)
+  gy = torch.randn(M, d, generator=g).bfloat16()
+  norm = RMSNorm(d).cuda()
+  with torch.no_grad():
+    norm.weight.copy_(w0.cuda())
+
+  def ref(use_x, use_y):
+    xr, wr = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    tot = 0
+    if use_y:
+      tot = tot + (O.rmsnorm(xr, wr) * gy.float()).sum()
+    if use_x:
+      tot = tot + (xr * gx).sum()
+    tot.backward()
+    return xr.grad, wr.grad
+
+  for use_x, use_y in ((True, True), (False, True), (True, False)):
+    x = x0.cuda().requires_grad_(True)
+    norm.weight.grad = None
+    xa, y = Fn.NormFn.apply(x, norm.weight, norm)
+    assert xa.data_ptr() == x.data_ptr()  # an alias, not a copy
+    tot = 0
+    if use_y:
+      tot = tot + (y.float() * gy.cuda().float()).sum()
+    if use_x:
+      tot = tot + (xa * gx.cuda()).sum()
+    tot.backward()
+    rx, rw = ref(use_x, use_y)
+    assert relmax(x.grad, rx) < 2e-5, (use_x, use_y)
+    if use_y:
+      assert relmax(norm.weight.grad, rw) < 2e-5
+    else:
+      assert norm.weight.grad is None
+  x = x0.cuda().requires_grad_(True)
+  xa, _ = Fn.NormFn.apply(x, norm.weight, norm)
+  with pytest.raises(RuntimeError):
+    xa += 1.0
