@@ -132,17 +132,32 @@ def csrc_sha():
   return h.hexdigest()[:16]
 
 
-PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_pmc_gemm_traffic.json')
+def _pmc_profile():
+  """The committed PMC traffic profile to use: the newest profiles/r*_pmc_gemm_traffic.json taken on THIS tree's csrc (by hash); when
+  none matches, the newest one (pmc_traffic then reports why it is not used)."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_gemm_traffic.json')), reverse=True)
+  sha = csrc_sha()
+  for f in files:
+    try:
+      if json.load(open(f)).get('csrc_sha') == sha:
+        return f
+    except Exception:  # noqa: BLE001 - an unreadable profile is simply not the one
+      pass
+  return files[0] if files else os.path.join(ROOT, 'profiles', 'none_pmc_gemm_traffic.json')
+
+
 
 
 def pmc_traffic(family, config, tokens, n_layers):
   """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
-  (profiles/r03_pmc_gemm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM shape of the
+  (profiles/r<NN>_pmc_gemm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes, one row per GEMM shape of the
   160M / 32768-token step; tools/prof_traffic.py + tools/pmc_traffic_report.py).  bench.py cannot run the profiler on
   itself, so the figure is the profile's, averaged over the launches of one step - and ONLY when the profile was taken on
   this very tree (the profile records the sha of plainlm_amd/csrc): otherwise traffic stays null and the reason is stated."""
   if family not in ('gemm_nt', 'gemm_nt_fused', 'gemm_tn') or config != '160m' or tokens != 32768:
     return {}
+  PMC_PROFILE = _pmc_profile()
   if not os.path.exists(PMC_PROFILE):
     return {'traffic_note': 'no PMC profile committed for this workload'}
   prof = json.load(open(PMC_PROFILE))

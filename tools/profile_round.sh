@@ -15,6 +15,7 @@ python bench.py --config 420m --no-extras > $O/bench_420m.json 2> $O/bench_420m.
 python bench.py --doc-mask --no-extras > $O/bench_docmask.json 2> $O/bench_docmask.err; echo "bench doc-mask rc=$?"
 python bench.py --doc-mask --micro-batch 8 --no-extras > $O/bench_docmask_b8.json 2> $O/bench_docmask_b8.err; echo "bench doc-mask B=8 rc=$?"
 PLM_FORCE_REDUCER=1 python bench.py --no-extras > $O/bench_force_reducer.json 2> $O/bench_force_reducer.err; echo "bench 1-GPU reducer what-if rc=$?"
+PLM_FORCE_REDUCER=1 PLM_COMM_MODEL_GBPS=60 python bench.py --no-extras > $O/bench_force_reducer_60gbps.json 2> $O/bench_force_reducer_60gbps.err; echo "bench 1-GPU reducer what-if, windows at 60 GB/s rc=$?"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-extras > $R/$O/trace.log 2>&1; echo "trace rc=$?"
 python3 $R/tools/prof_kernels.py > $R/$O/order.log 2>&1; echo "order rc=$?"
