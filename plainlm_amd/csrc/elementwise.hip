@@ -839,27 +839,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float step = lr / bc1;
   const float decay = 1.f - lr * wd;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // 16 bytes per lane and array where the span allows it (every span FlatAdamW passes starts on a 16-byte boundary; a ragged tail
-  // and misaligned callers take the scalar loop)
-  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
-  const int64_t n4 = vec ? n >> 2 : 0;
-  for (int64_t i = tid; i < n4; i += stride) {
-    f32x4_t pv = *reinterpret_cast<const f32x4_t*>(p + 4 * i);
-    const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + 4 * i);
-    f32x4_t mv = *reinterpret_cast<const f32x4_t*>(m + 4 * i), vv = *reinterpret_cast<const f32x4_t*>(v + 4 * i);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float me = mv[e], ve = vv[e];
-      pv[e] = adamw_elem(pv[e], gv[e], me, ve, cs, b1, b2, eps, decay, step, bc2_sqrt);
-      mv[e] = me;
-      vv[e] = ve;
-    }
-    *reinterpret_cast<f32x4_t*>(m + 4 * i) = mv;
-    *reinterpret_cast<f32x4_t*>(v + 4 * i) = vv;
-    *reinterpret_cast<f32x4_t*>(p + 4 * i) = pv;
-  }
-  for (int64_t i = 4 * n4 + tid; i < n; i += stride) {
+  // one element per thread, blocks in memory order (see elementwise_grid: measured 29 % faster than a capped grid with a stride loop;
+  // a float4-per-thread form of this kernel measured 0.94 ms against 0.73 ms for 162 M parameters, round 4)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float mi = m[i], vi = v[i];
     p[i] = adamw_elem(p[i], g[i], mi, vi, cs, b1, b2, eps, decay, step, bc2_sqrt);
     m[i] = mi;
