@@ -251,6 +251,8 @@ int plm_comm_split(plm_comm_t* parent, plm_comm_t** child, int max_ctas);
 int plm_comm_destroy(plm_comm_t* comm);
 /* in-place all-reduce-mean of a fp32 span on `stream` (the side stream owned by the caller) */
 int plm_comm_allreduce_avg_f32(plm_comm_t* comm, float* buf, int64_t count, void* stream);
+/* the same mean as reduce-scatter + all-gather in place (one-hop collectives over all xGMI links; opt-in, PLM_COMM_ALGO=rsag) */
+int plm_comm_rsag_avg_f32(plm_comm_t* comm, float* buf, int64_t count, void* stream);
 int plm_comm_broadcast_f32(plm_comm_t* comm, float* buf, int64_t count, int root, void* stream);
 
 /* ---- hardware probes used by the GPU tests (semantics of gfx950 instructions the kernels rely on)

@@ -93,6 +93,7 @@ SIGNATURES = {
   'plm_comm_split': (_I, [_P, C.POINTER(_P), _I]),
   'plm_comm_destroy': (_I, [_P]),
   'plm_comm_allreduce_avg_f32': (_I, [_P, _P, _I64, _P]),
+  'plm_comm_rsag_avg_f32': (_I, [_P, _P, _I64, _P]),
   'plm_comm_broadcast_f32': (_I, [_P, _P, _I64, _I, _P]),
   'plm_probe_ds_read_tr16': (_I, [_P, _P]),
   'plm_probe_mfma32': (_I, [_P, _P, _P, _P]),

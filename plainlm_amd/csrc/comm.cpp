@@ -115,6 +115,27 @@ extern "C" int plm_comm_allreduce_avg_f32(plm_comm_t* c, float* buf, int64_t cou
   return PLM_OK;
 }
 
+// The same mean as plm_comm_allreduce_avg_f32, spelled as reduce-scatter + all-gather in place (on a fully connected
+// xGMI node a one-hop reduce-scatter / all-gather pair uses all 7 links of a GPU at once, a single ring one link each way; which of the
+// two RCCL's own ncclAllReduce picks depends on its tuning tables).  The span is cut into `world` equal chunks (rank r reduces chunk r);
+// the count % world elements left over go through a small all-reduce.  Opt-in (PLM_COMM_ALGO=rsag): no multi-GPU run has compared them.
+extern "C" int plm_comm_rsag_avg_f32(plm_comm_t* c, float* buf, int64_t count, void* stream) {
+  if (!c || !buf || count < 0) {
+    plm_set_error("plm_comm_rsag_avg_f32: bad arguments");
+    return PLM_E_INVALID;
+  }
+  if (count == 0) return PLM_OK;
+  const int64_t chunk = count / c->world, tail = count - chunk * c->world;
+  hipStream_t s = (hipStream_t)stream;
+  if (chunk > 0) {
+    float* mine = buf + (int64_t)c->rank * chunk;  // in-place forms: recvbuff = sendbuff + rank * recvcount / sendbuff = recvbuff + rank * sendcount
+    PLM_NCCL(ncclReduceScatter(buf, mine, (size_t)chunk, ncclFloat32, ncclAvg, c->comm, s), "ncclReduceScatter");
+    PLM_NCCL(ncclAllGather(mine, buf, (size_t)chunk, ncclFloat32, c->comm, s), "ncclAllGather");
+  }
+  if (tail > 0) PLM_NCCL(ncclAllReduce(buf + chunk * c->world, buf + chunk * c->world, (size_t)tail, ncclFloat32, ncclAvg, c->comm, s), "ncclAllReduce (tail)");
+  return PLM_OK;
+}
+
 extern "C" int plm_comm_broadcast_f32(plm_comm_t* c, float* buf, int64_t count, int root, void* stream) {
   if (!c || !buf || count < 0 || root < 0 || root >= c->world) {
     plm_set_error("plm_comm_broadcast_f32: bad arguments");

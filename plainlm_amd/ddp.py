@@ -83,8 +83,11 @@ class RcclComm:
     return RcclComm(self.rank, self.world_size, self.device_index, max_ctas=max_ctas, _handle=child)
 
   def allreduce_avg_(self, span, stream):
-    _lib.check(self.lib.plm_comm_allreduce_avg_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(),
-                                                   C.c_void_p(stream.cuda_stream)), 'plm_comm_allreduce_avg_f32')
+    # PLM_COMM_ALGO=rsag: the mean as reduce-scatter + all-gather in place (one-hop collectives over all xGMI links) instead of RCCL's
+    # own all-reduce; opt-in until a multi-GPU run has compared the two
+    fn, name = ((self.lib.plm_comm_rsag_avg_f32, 'plm_comm_rsag_avg_f32') if os.environ.get('PLM_COMM_ALGO') == 'rsag' else
+                (self.lib.plm_comm_allreduce_avg_f32, 'plm_comm_allreduce_avg_f32'))
+    _lib.check(fn(self.handle, C.c_void_p(span.data_ptr()), span.numel(), C.c_void_p(stream.cuda_stream)), name)
 
   def broadcast_(self, span, root, stream):
     _lib.check(self.lib.plm_comm_broadcast_f32(self.handle, C.c_void_p(span.data_ptr()), span.numel(), root,

@@ -181,8 +181,9 @@ def test_bench_metric_definition(monkeypatch):
   assert len(bench.csrc_sha()) == 16 and bench.physical_cores() >= 1
   # the launch plan bench.py sums over must match the rows of the COMMITTED profile whatever this tree's hash is (a plan / row-name
   # mismatch once took the whole benchmark down on the GPU box, where the hashes did match)
-  if os.path.exists(bench.PMC_PROFILE):
-    monkeypatch.setattr(bench, 'csrc_sha', lambda: json.load(open(bench.PMC_PROFILE))['csrc_sha'])
+  prof = bench._pmc_profile()  # the newest committed profile (the one of this tree's csrc when there is one)
+  if os.path.exists(prof):
+    monkeypatch.setattr(bench, 'csrc_sha', lambda: json.load(open(prof))['csrc_sha'])
     for fam in ('gemm_nt', 'gemm_nt_fused', 'gemm_tn'):
       tr = bench.pmc_traffic(fam, '160m', 32768, 12)
       assert tr.get('traffic', 0) > tr.get('algorithmic_bytes', 1) > 0, (fam, tr)

@@ -579,6 +579,18 @@ def test_rccl_reducer_single_rank(P, mdl):
     red.finish()
     torch.cuda.synchronize()
     assert seen == [] and ops.cu_reserve() == 0 and torch.equal(m._flat_grad, want)
+    # the reduce-scatter + all-gather spelling of the mean (PLM_COMM_ALGO=rsag): one rank, so again the identity - spans that do and do not
+    # divide by the world size take the same calls
+    os.environ['PLM_COMM_ALGO'] = 'rsag'
+    try:
+      m.sink.begin_window()
+      red.begin(sync=True)
+      m.loss(ids, tgt).backward()
+      red.finish()
+      torch.cuda.synchronize()
+      assert torch.equal(m._flat_grad, want)
+    finally:
+      del os.environ['PLM_COMM_ALGO']
     # measured durations: with the model switched off, begin() folds the previous step's collectives into the estimate
     red.model_gbps = None
     red.begin(sync=True)
