@@ -450,6 +450,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       continue;
     }
     // ---- epilogue: 32-row x 64-col pieces through this wave's private 4 KiB scratch ----
+    // alpha is 1 for every launch of the step but lm_head's dX: the 4 * AF * 2 * NBF * 4 multiplies are taken only when a device scalar
+    // was passed (x * 1.0f is exact, so the bits do not depend on which way the branch goes)
+    if (alpha_dev != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4 * AF; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * NBF; ++j) acc4[i][j] *= alpha;
+    }
 #pragma unroll
     for (int mf = 0; mf < 2 * AF; ++mf) {
       const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
               bf16x4_t dxo, dzo;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float gf = bf2f(f2bf(acc4[fi][bq * 2 + sc][e] * alpha));  // d(act) as the GEMM would have stored it
+                const float gf = bf2f(f2bf(acc4[fi][bq * 2 + sc][e]));  // d(act) as the GEMM would have stored it
                 const float xf = bf2f(xv[e]), zf = bf2f(zv[e]);
                 const float sig = plm_sigmoid(xf);
                 const bf16_t sv = f2bf(xf * sig);
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
             for (int sc = 0; sc < 2; ++sc) {  // 16-column half of the 32-column block: this lane holds columns 4 q .. 4 q + 3 of it
               bf16x4_t o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc4[(mf / AF) * 2 * AF + (mf % AF) * 2 + sr][bh * 2 + sc][e] * alpha);
+              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc4[(mf / AF) * 2 * AF + (mf % AF) * 2 + sr][bh * 2 + sc][e]);
               const int row = sr * 16 + l15, c = bq * 4 + sc * 2 + (q >> 1);
               *reinterpret_cast<bf16x4_t*>(epi + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = o;
             }
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
             const int fi = (mf / AF) * 2 * AF + (mf % AF) * 2 + sr;
             bf16x4_t o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = plm_swiglu_bf16(f2bf(acc4[fi][sc][e] * alpha), f2bf(acc4[fi][2 + sc][e] * alpha));
+            for (int e = 0; e < 4; ++e) o[e] = plm_swiglu_bf16(f2bf(acc4[fi][sc][e]), f2bf(acc4[fi][2 + sc][e]));
             const int row = sr * 16 + l15, c = sc * 2 + (q >> 1);
             *reinterpret_cast<bf16x4_t*>(epi + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = o;
           }
