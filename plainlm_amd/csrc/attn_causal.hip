@@ -26,28 +26,14 @@
 
 #include "attn_common.h"
 
-// Block -> (row tile of RB rows, head, batch).  map 0: tile-major, heaviest (latest) tiles first - see attn_block() in attn.hip.
-// map 1 (XCD-aware): workgroups go to the 8 XCDs round-robin by block index, so XCD x = blockIdx % 8 gets the heads {x, x + 8, ...} and runs
-// ALL row tiles of one head back to back (heaviest first) before the next head: the tiles of a head stream the same K / V (Q / dO) rows,
-// and with 8 heads in flight per XCD (2 MB) they meet in its 4 MB L2 instead of each fetching them over the fabric.
+// Block -> (row tile of RB rows, head, batch), heaviest (latest) tiles first: see attn_block() in attn.hip.  (Head-major orders that let the
+// tiles of a head meet in their XCD's L2 are slower - load balance is worth more than L2 hits: profiles/r04_attn_pingpong.txt section 3.)
 template <int RB>
-__device__ __forceinline__ void attn_block2(int T, int nh, int map, int& tile, int& h, int& b) {
+__device__ __forceinline__ void attn_block2(int T, int nh, int& tile, int& h, int& b) {
   const int ntile = (T + RB - 1) / RB;
   const int nbh = gridDim.x / ntile;
-  int bh;
-  if (map == 1 && (nbh & 7) == 0) {
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    tile = j % ntile;
-    bh = (j / ntile) * 8 + x;
-  } else if (map >= 2 && (nbh & 7) == 0 && (nbh >> 3) % map == 0) {  // groups of `map` heads per XCD, heaviest tiles first inside a group
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int per = map * ntile, grp_ = j / per, r = j - grp_ * per;
-    tile = r / map;
-    bh = (grp_ * map + r % map) * 8 + x;
-  } else {
-    bh = blockIdx.x % nbh;
-    tile = blockIdx.x / nbh;
-  }
+  const int bh = blockIdx.x % nbh;
+  tile = blockIdx.x / nbh;
   h = bh % nh;
   b = bh / nh;
 }
@@ -73,14 +59,14 @@ enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };  // a 32-row block on a key tile: a
 // =============================================================================================
 template <int NST>
 __global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                                 float* __restrict__ lse, int T, int nh, int map) {
+                                                                 float* __restrict__ lse, int T, int nh) {
   constexpr int KT = 64;
   constexpr int TILE = KT * 128;  // 8 KiB
   constexpr int QB = 256;
   __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];  // [stage][K|V]
 
   int tile_, h, b;
-  attn_block2<QB>(T, nh, map, tile_, h, b);
+  attn_block2<QB>(T, nh, tile_, h, b);
   const int qt = (T + QB - 1) / QB - 1 - tile_;
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
@@ -277,14 +263,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
                                                               const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, const float* __restrict__ rcos,
                                                               const float* __restrict__ rsin, uint16_t* __restrict__ dqkv, int T, int nh,
-                                                              float dsign, int map) {  // delta is published as dsign * delta (-1 for the ping-pong dK/dV kernel)
+                                                              float dsign) {  // delta is published as dsign * delta (-1: what the dK/dV kernel reads into its dP accumulators)
   constexpr int KT = 64;
   constexpr int TILE = KT * 128;
   constexpr int QB = 256;
   __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];  // [stage][K|V]
 
   int tile_, h, b;
-  attn_block2<QB>(T, nh, map, tile_, h, b);
+  attn_block2<QB>(T, nh, tile_, h, b);
   const int qt = (T + QB - 1) / QB - 1 - tile_;
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
@@ -466,9 +452,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
 // =============================================================================================
 template <int NST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                const float* __restrict__ lse, const float* __restrict__ ndelta,
                                                                 const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                                uint16_t* __restrict__ dqkv, int T, int nh, int map) {
+                                                                uint16_t* __restrict__ dqkv, int T, int nh) {
   constexpr int QT = 64;
   constexpr int TILE = QT * 128;          // 8 KiB
   constexpr int STAGE = 2 * TILE + 512;   // Q | dO | statistics (lse[64], delta[64])
@@ -476,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
   __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
 
   int kt, h, b;  // key tile 0 meets every query tile: heaviest first
-  attn_block2<KB>(T, nh, map, kt, h, b);
+  attn_block2<KB>(T, nh, kt, h, b);
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -487,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
   const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
   const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
   const float* lrow = lse + ((int64_t)b * nh + h) * T;
-  const float* drow = delta + ((int64_t)b * nh + h) * T;
+  const float* drow = ndelta + ((int64_t)b * nh + h) * T;
   const float scale = 0.125f, c2 = scale * LOG2E;
 
   bf16x8_t kf[4], vf[4];
@@ -544,12 +530,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
         qfr[ks] = frag_rows(sQ, qb * 32 + l31, ks, hi);
         dofr[ks] = frag_rows(sDO, qb * 32 + l31, ks, hi);
       }
-      f32x4_t L4[4], D4[4];
+      f32x4_t L4[4];
+      f32x16_t s, dp;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ql0 = qb * 32 + 8 * g + 4 * hi;
         L4[g] = *reinterpret_cast<const f32x4_t*>(sL + ql0);  // base-2 LSE
-        D4[g] = *reinterpret_cast<const f32x4_t*>(sD + ql0);
+        const f32x4_t nd = *reinterpret_cast<const f32x4_t*>(sD + ql0);  // -delta: the dP accumulators start from it (dP' = dP - delta)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -558,13 +547,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
           dotr[db][s2] = frag_cols(sDO, db, qb * 32 + s2 * 16 + 4 * hi, lane);
           qtr[db][s2] = frag_cols(sQ, db, qb * 32 + s2 * 16 + 4 * hi, lane);
         }
-      f32x16_t s, dp;
       zero16(s);
-      zero16(dp);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(qfr[ks], kf[ks], s);       // S[q][kv]
-        dp = mfma32(dofr[ks], vf[ks], dp);    // dP[q][kv]
+        dp = mfma32(dofr[ks], vf[ks], dp);    // dP'[q][kv]
       }
       bf16x8_t pf[2], dsf[2];
 #pragma unroll
@@ -577,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
             const int c = qb * 32 + 8 * g + e;
             p = ((c >= c_lo) && (c < c_end)) ? p : 0.f;
           }
-          const float dsv = p * (dp[r] - D4[g][e]);  // the 1/sqrt(hd) factor (a power of two: exact) is applied once, to dK, in the epilogue
+          const float dsv = p * dp[r];  // the 1/sqrt(hd) factor (a power of two: exact) is applied once, to dK, in the epilogue
           pf[r >> 3][r & 7] = f2bf(p);
           dsf[r >> 3][r & 7] = f2bf(dsv);
         }
@@ -658,473 +645,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
 }
 
 // =============================================================================================
-// backward dK / dV, ping-pong form (round 4).  What the generation-two kernel above leaves on the table: a wave's stream is
-// {S, dP MFMAs} -> {exp / dS arithmetic} -> {dV, dK MFMAs}, two such waves share a SIMD, and nothing makes one wave's matrix phase coincide
-// with the other's arithmetic phase - the kernel's time is the SUM of its MFMA, VALU-issue and LDS time (mfma_util 0.30).  Here ONE
-// workgroup of 8 waves owns the 128-key tile: waves w and w + 4 (same SIMD) hold the same 32 key rows and take alternate 64-query tiles,
-// every 32-query block is two phases -
-//     X(k) = dV / dK MFMAs of block k - 1, then S / dP MFMAs of block k          (16 MFMAs, nothing else)
-//     Y(k) = transposed Q / dO fragment reads of block k, P and dS arithmetic, then the row fragments + statistics of block k + 1
-// - and a workgroup barrier after every phase keeps group 1 (waves 4-7) exactly one phase behind group 0: while one wave of a SIMD feeds the
-// matrix pipe from registers the other one owns the VALU and the LDS.  The two groups' partial dK / dV meet once, in the epilogue (fixed
-// order: deterministic).  -delta (published negated by the dQ kernel for this kernel) is read from LDS straight into the dP accumulators,
-// so dS = P * dP' costs one multiply.
-// Ring: tile j is issued LEAD steps before step j (one step = one block of each group), awaited at the end of step j - 2, first read in
-// step j - 1, last read in step j + 1, its slot re-issued in step j + NST - LEAD >= j + 3.
-// =============================================================================================
-struct TileDma8 {  // a [64 rows][64 d] tile by 8 waves: ONE LDS-DMA instruction per wave (rows 8 wave .. 8 wave + 7)
-  int row, coff;
-  unsigned boff;
-  __device__ __forceinline__ void init(int wave, int lane, int64_t ld) {
-    row = wave * 8 + (lane >> 3);
-    coff = rs_logical_chunk(row, lane & 7) * 8;
-    boff = (unsigned)((row * ld + coff) * 2);
-  }
-  __device__ __forceinline__ void issue(char* dst_tile, const uint16_t* src, int64_t ld, int last_row, int wave) const {
-    dma16_asm(src + (int64_t)min(row, last_row) * ld + coff, dst_tile + wave * 1024);
-  }
-  __device__ __forceinline__ void issue_full(char* dst_tile, const uint16_t* src, int wave) const { dma16_saddr_asm(src, boff, dst_tile + wave * 1024); }
-};
-constexpr int ATTN_PP_DMA_PER_STAGE = 2;  // Q piece + dO piece per wave and tile; wave 0 adds ATTN_DMA_STATS
-
-__device__ __forceinline__ void attn_pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
-__device__ unsigned long long g_pp_tl[2][256];  // timeline of one workgroup's waves 0 and 4 (PLM_ATTN_PP=2: debug builds of the kernel below)
-#define PP_TL(i)                                                 \
-  if (TL && blockIdx.x == TL_BLOCK && lane == 0 && (i) < 64) \
-  tlbuf[wave * 64 + (i)] = __builtin_readcyclecounter()
-constexpr int TL_BLOCK = 1200;
-
-template <int NST, bool TL, bool PK>
-__global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                                 const float* __restrict__ lse, const float* __restrict__ ndelta,
-                                                                 const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                                 uint16_t* __restrict__ dqkv, int T, int nh, int prio, int map) {
-  constexpr int QT = 64;
-  constexpr int TILE = QT * 128;          // 8 KiB
-  constexpr int STAGE = 2 * TILE + 512;   // Q | dO | statistics (lse[64], -delta[64])
-  constexpr int KB = 128;
-  constexpr int LEAD = 4;
-  static_assert(NST >= LEAD + 3, "a slot is re-issued no earlier than two steps after its tile's last read");
-  static_assert(NST * STAGE >= 64 * 1024 + 8 * 4096, "the epilogue's exchange + row-staging regions live in the ring");
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
-  __shared__ unsigned long long tlbuf[TL ? 512 : 1];
-
-  int kt, h, b;  // key tile 0 meets every query tile: heaviest first
-  attn_block2<KB>(T, nh, map, kt, h, b);
-  const int dm = nh * HD, ld = 3 * dm;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2, w4 = wave & 3;
-  if (TL) {
-    tlbuf[t] = 0;
-    __syncthreads();
-  }
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int kv0 = kt * KB, kvw0 = kv0 + w4 * 32;
-  const int kvrow = kvw0 + l31;
-  const bool kvalid = kvrow < T;
-  const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
-  const uint16_t* dobase = dout + (int64_t)b * T * dm + h * HD;
-  const float* lrow = lse + ((int64_t)b * nh + h) * T;
-  const float* drow = ndelta + ((int64_t)b * nh + h) * T;
-  const float scale = 0.125f, c2 = scale * LOG2E;
-  PP_TL(0);
-
-  bf16x8_t kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
-    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
-    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
-  }
-  const int nqt = (T + QT - 1) / QT;
-  const int jq_lo = kv0 / QT;
-  const int n = nqt - jq_lo;  // query tiles this key tile meets
-  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
-               "v"(vf[3]));  // every ordinary load is consumed before the first DMA is in flight
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PP_TL(1);
-
-  f32x16_t dk[2], dv[2];
-  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
-
-  TileDma8 dma, dmad;
-  dma.init(wave, lane, ld);
-  dmad.init(wave, lane, dm);
-  auto stage = [&](int jr) {  // 2 LDS-DMA instructions per wave, + 2 sixteen-lane ones on wave 0
-    const int qt0 = (jq_lo + jr) * QT;
-    char* dst = smem + (jr % NST) * STAGE;
-    if (qt0 + QT <= T) {
-      dma.issue_full(dst, base + (int64_t)qt0 * ld, wave);
-      dmad.issue_full(dst + TILE, dobase + (int64_t)qt0 * dm, wave);
-    } else {
-      dma.issue(dst, base + (int64_t)qt0 * ld, ld, T - 1 - qt0, wave);
-      dmad.issue(dst + TILE, dobase + (int64_t)qt0 * dm, dm, T - 1 - qt0, wave);
-    }
-    if (wave == 0 && lane < 16) {  // 64 floats = 16 lanes x 16 bytes per statistic (T % 4 == 0 is checked on the host)
-      const int q = min(qt0 + lane * 4, T - 4);
-      dma16_asm(lrow + q, dst + 2 * TILE);
-      dma16_asm(drow + q, dst + 2 * TILE + 256);
-    }
-  };
-  // this wave's pieces of every tile but the `younger` most recently issued ones have landed
-  auto wait_tiles = [&](int younger) {
-    if (wave == 0) {
-      constexpr int W0 = ATTN_PP_DMA_PER_STAGE + ATTN_DMA_STATS;
-      if (younger >= 2) attn_wait_vm<2 * W0>();
-      else if (younger == 1) attn_wait_vm<W0>();
-      else attn_wait_vm<0>();
-    } else {
-      if (younger >= 2) attn_wait_vm<2 * ATTN_PP_DMA_PER_STAGE>();
-      else if (younger == 1) attn_wait_vm<ATTN_PP_DMA_PER_STAGE>();
-      else attn_wait_vm<0>();
-    }
-  };
-
-  // Block k of this group = 32-query block (k & 1) of tile jr = 2 (k >> 1) + grp.  Blocks [0, ka) lie entirely before this wave's first key
-  // (P = 0: barriers and DMA duties only), blocks [ka, kb) are computed, masked where the diagonal or the end of the sequence crosses them.
-  const int kb_ = 2 * ((n - grp + 1) / 2);  // blocks of this group's tiles
-  int ka = 0, kb = 0;
-  if (kvw0 < T) {
-    kb = kb_;
-    // first k with  qs0 + 31 >= kvw0,  qs0 = (jq_lo + 2 (k >> 1) + grp) * 64 + (k & 1) * 32
-    const int d = kvw0 - 31 - (jq_lo + grp) * QT;  // qs0 >= d  with qs0 = 128 (k >> 1) + 32 (k & 1) relative to the group's first tile
-    if (d > 0) {
-      const int pr = d / 128, rem = d - pr * 128;
-      ka = 2 * pr + (rem <= 0 ? 0 : rem <= 32 ? 1 : 2);
-    }
-    ka = min(ka, kb);
-  }
-  auto masked = [&](int k) -> bool {
-    const int qs0 = (jq_lo + 2 * (k >> 1) + grp) * QT + (k & 1) * 32;
-    return qs0 < kvw0 + 31 || qs0 + 32 > T;
-  };
-
-  f32x16_t s, dp;
-  bf16x8_t qfr[4], dofr[4], dotr[2][2], qtr[2][2], pf[2], dsf[2];
-  f32x4_t L4[4];
-  zero16(s);
-  zero16(dp);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    pf[i] = zero_bf16x8();
-    dsf[i] = zero_bf16x8();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      dotr[i][j] = zero_bf16x8();  // the first matrix phase adds 0 x 0 to dV / dK
-      qtr[i][j] = zero_bf16x8();
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) L4[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // Per-lane byte offsets of every fragment read inside a tile, computed ONCE (opaque to the compiler, which otherwise re-derives them from
-  // the lane id in every phase: 45 VALU instructions per block); a block's reads are (offset + wave-uniform block base) + immediate.
-  unsigned o_r[4], o_c[2][2], o_s;
-  {
-    const int ib = (lane >> 4) & 1, t16 = lane & 15, sub = t16 & 3;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) o_r[ks] = (unsigned)rs_off(l31, ks * 2 + hi);
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) o_c[db][j] = (unsigned)(rs_off(4 * hi + (t16 >> 2) + 8 * j, (db * 2 + ib) * 2 + (sub >> 1)) + (sub & 1) * 8);
-    o_s = (unsigned)(16 * hi);
-    asm volatile("; lane offsets" : "+v"(o_r[0]), "+v"(o_r[1]), "+v"(o_r[2]), "+v"(o_r[3]), "+v"(o_c[0][0]), "+v"(o_c[0][1]), "+v"(o_c[1][0]),
-                 "+v"(o_c[1][1]), "+v"(o_s));
-  }
-  auto block_base = [&](int k) -> unsigned { return (unsigned)(((2 * (k >> 1) + grp) % NST) * STAGE + (k & 1) * 4096); };  // Q rows of block k
-  // Reads of a block past the group's last one, or of a tile that has not landed, return garbage nobody uses (addresses stay inside the ring).
-  auto read_stats = [&](int k) {  // statistics of block k: LSE, and -delta straight into the dP accumulators
-    const char* p = smem + (o_s + (unsigned)(((2 * (k >> 1) + grp) % NST) * STAGE + 2 * TILE + (k & 1) * 128));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {  // query r = 4g + e of this lane is tile row qb*32 + 8g + e + 4*hi
-      L4[g] = *reinterpret_cast<const f32x4_t*>(p + g * 32);  // base-2 LSE
-      const f32x4_t nd = *reinterpret_cast<const f32x4_t*>(p + 256 + g * 32);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];  // dP' = -delta + dO V^T
-    }
-  };
-  auto read_rows = [&](int k, int ks0) {  // row fragments ks0, ks0 + 1 of block k: operands of its S / dP MFMAs
-    const unsigned bb = block_base(k);
-#pragma unroll
-    for (int ks = ks0; ks < ks0 + 2; ++ks) {
-      const char* p = smem + (o_r[ks] + bb);
-      qfr[ks] = *reinterpret_cast<const bf16x8_t*>(p);
-      dofr[ks] = *reinterpret_cast<const bf16x8_t*>(p + TILE);
-    }
-  };
-  auto read_cols = [&](int k) {  // transposed fragments of block k: operands of its dV / dK MFMAs
-    const unsigned bb = block_base(k);
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const char* p0 = smem + (o_c[db][0] + bb);
-      const char* p1 = smem + (o_c[db][1] + bb);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        qtr[db][s2] = join_tr(lds_read_tr16(p0 + s2 * 2048), lds_read_tr16(p1 + s2 * 2048));
-        dotr[db][s2] = join_tr(lds_read_tr16(p0 + TILE + s2 * 2048), lds_read_tr16(p1 + TILE + s2 * 2048));
-      }
-    }
-  };
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  f32x2_t c2v = {c2, c2};
-  asm volatile("; scale pair" : "+v"(c2v));  // a plain VGPR pair: no op_sel / SGPR forms in the packed instructions below
-  auto softmax_bwd = [&](int k, auto mask_tag) {
-    constexpr bool MASK = decltype(mask_tag)::value;
-    const int qb = k & 1;
-    const int qt0 = (jq_lo + 2 * (k >> 1) + grp) * QT;
-    const int c_lo = kvrow - qt0 - 4 * hi, c_end = T - qt0 - 4 * hi;  // visible iff  c_lo <= qb*32 + 8g + e < c_end
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const int r = 4 * g + e;
-        float p0, p1, d0, d1;
-        if (PK) {  // v_pk_fma_f32 / v_pk_mul_f32: the same IEEE operations, two per instruction
-          const f32x2_t sv = {s[r], s[r + 1]}, lv = {L4[g][e], L4[g][e + 1]};
-          const f32x2_t x = __builtin_elementwise_fma(sv, c2v, -lv);
-          p0 = fast_exp2(x[0]);
-          p1 = fast_exp2(x[1]);
-        } else {
-          p0 = fast_exp2(__builtin_fmaf(s[r], c2, -L4[g][e]));
-          p1 = fast_exp2(__builtin_fmaf(s[r + 1], c2, -L4[g][e + 1]));
-        }
-        if (MASK) {
-          const int c = qb * 32 + 8 * g + e;
-          p0 = ((c >= c_lo) && (c < c_end)) ? p0 : 0.f;
-          p1 = ((c + 1 >= c_lo) && (c + 1 < c_end)) ? p1 : 0.f;
-        }
-        if (PK) {
-          const f32x2_t pv = {p0, p1}, dv2 = {dp[r], dp[r + 1]};
-          const f32x2_t dd = pv * dv2;
-          d0 = dd[0];
-          d1 = dd[1];
-        } else {
-          d0 = p0 * dp[r];  // the 1/sqrt(hd) factor (a power of two: exact) is applied once, to dK, in the epilogue
-          d1 = p1 * dp[r + 1];
-        }
-        pf[r >> 3][r & 7] = f2bf(p0);
-        pf[r >> 3][(r & 7) + 1] = f2bf(p1);
-        dsf[r >> 3][r & 7] = f2bf(d0);
-        dsf[r >> 3][(r & 7) + 1] = f2bf(d1);
-      }
-  };
-  // matrix phase X(k): dV / dK of block k - 1 (operands in registers since Y(k - 1)), S / dP of block k; block k's row fragments are read here, in
-  // two halves, into the registers the first half of the dV / dK MFMAs has released - the MFMAs cover the reads' latency.
-  auto phase_x = [&](int k) {
-    __builtin_amdgcn_sched_barrier(0);
-    if (prio & 1) __builtin_amdgcn_s_setprio(1);
-    if (!(prio & 32)) read_rows(k, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(prio & 64)) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      dv[db] = mfma32(dotr[db][0], pf[0], dv[db]);   // dV^T[d][kv]
-      dk[db] = mfma32(qtr[db][0], dsf[0], dk[db]);   // dK^T[d][kv]
-    }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(prio & 32)) read_rows(k, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(prio & 64)) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      dv[db] = mfma32(dotr[db][1], pf[1], dv[db]);
-      dk[db] = mfma32(qtr[db][1], dsf[1], dk[db]);
-    }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(prio & 64)) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      s = mfma32(qfr[ks], kf[ks], s);       // S[q][kv]
-      dp = mfma32(dofr[ks], vf[ks], dp);    // dP'[q][kv]
-    }
-    }
-    if (prio & 1) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // arithmetic phase Y(k): P and dS of block k, then its transposed fragments and the next block's statistics
-  auto phase_y = [&](int k) {
-    __builtin_amdgcn_sched_barrier(0);
-    if (prio & 2) __builtin_amdgcn_s_setprio(1);
-    if (!(prio & 8)) {
-    if (masked(k)) softmax_bwd(k, std::true_type{});
-    else softmax_bwd(k, std::false_type{});
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(prio & 16)) {
-    read_cols(k);
-    read_stats(k + 1);
-    }
-    if (prio & 2) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto step_begin = [&](int step) {
-    if (step + LEAD < n) stage(step + LEAD);
-  };
-  auto step_end = [&](int step) {
-    wait_tiles(min(n - 1, step + LEAD) - (step + 2));  // tile step + 2 (first read in step + 1)
-    attn_pp_barrier();
-  };
-
-#pragma unroll
-  for (int jr = 0; jr < LEAD; ++jr)
-    if (jr < n) stage(jr);
-  wait_tiles(min(n, LEAD) - 2);  // tiles 0 and 1
-  attn_pp_barrier();
-  PP_TL(2);
-  const int K = 2 * ((n + 1) / 2);  // steps 0 .. K: blocks of group 0 (group 1 has as many, or two fewer), + the last dV / dK phase
-  int step = 0;
-  if ((prio & 4) && grp == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched half
-  if (grp == 0) {  // step = X(step) | Y(step)
-    for (; step < ka; ++step) {
-      step_begin(step);
-      attn_pp_barrier();
-      step_end(step);
-    }
-    read_stats(ka);
-    for (; step < kb; ++step) {
-      step_begin(step);
-      PP_TL(8 + step * 4);
-      phase_x(step);
-      PP_TL(9 + step * 4);
-      attn_pp_barrier();
-      PP_TL(10 + step * 4);
-      phase_y(step);
-      PP_TL(11 + step * 4);
-      step_end(step);
-    }
-    step_begin(step);
-    phase_x(step);  // dV / dK of the last block (its S / dP half works on garbage)
-    attn_pp_barrier();
-    step_end(step);
-    ++step;
-  } else {  // step = Y(step - 1) | X(step): one phase behind group 0
-    for (; step < ka; ++step) {
-      step_begin(step);
-      attn_pp_barrier();
-      step_end(step);
-    }
-    step_begin(step);
-    read_stats(ka);
-    attn_pp_barrier();
-    phase_x(step);
-    step_end(step);
-    ++step;
-    for (; step <= kb; ++step) {
-      step_begin(step);
-      PP_TL(8 + step * 4);
-      phase_y(step - 1);
-      PP_TL(9 + step * 4);
-      attn_pp_barrier();
-      PP_TL(10 + step * 4);
-      phase_x(step);
-      PP_TL(11 + step * 4);
-      step_end(step);
-    }
-  }
-  for (; step <= K; ++step) {
-    step_begin(step);
-    attn_pp_barrier();
-    step_end(step);
-  }
-  PP_TL(3);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  attn_pp_barrier();  // nobody reads the ring any more
-
-  // the groups' partial sums meet: group 1 hands its dV to group 0, group 0 its dK to group 1 (8 KiB per wave, lane-linear)
-  {
-    float* xo = reinterpret_cast<float*>(smem + wave * 8192) + lane * 4;
-    const f32x16_t* give = grp == 0 ? dk : dv;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4_t v4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = give[db][4 * g + e];
-        *reinterpret_cast<f32x4_t*>(xo + (db * 4 + g) * 256) = v4;
-      }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  attn_pp_barrier();
-  f32x16_t acc[2];
-  {
-    const float* xi = reinterpret_cast<const float*>(smem + (wave ^ 4) * 8192) + lane * 4;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4_t v4 = *reinterpret_cast<const f32x4_t*>(xi + (db * 4 + g) * 256);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[db][4 * g + e] = (grp == 0 ? dv[db][4 * g + e] + v4[e] : v4[e] + dk[db][4 * g + e]);  // group 0's part first
-      }
-  }
-  const RowStage rs{smem + 64 * 1024 + wave * 4096, lane};
-  if (grp == 0) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4_t ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = f2bf(acc[db][4 * g + e]);
-        rs.put(l31, hi, db * 4 + g, ov);
-      }
-    rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, 2 * dm + h * HD);
-  } else {
-    const int trow = min(kvrow, T - 1) * 32;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
-        const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
-        const float a0 = acc[db][4 * g + 0] * scale, b0 = acc[db][4 * g + 1] * scale, a1 = acc[db][4 * g + 2] * scale, b1 = acc[db][4 * g + 3] * scale;
-        bf16x4_t ok;  // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
-        ok[0] = f2bf(a0 * c0 + b0 * s0);
-        ok[1] = f2bf(b0 * c0 - a0 * s0);
-        ok[2] = f2bf(a1 * c1 + b1 * s1);
-        ok[3] = f2bf(b1 * c1 - a1 * s1);
-        rs.put(l31, hi, db * 4 + g, ok);
-      }
-    rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, dm + h * HD);
-  }
-  PP_TL(4);
-  if (TL && blockIdx.x == TL_BLOCK) {
-    __syncthreads();
-    g_pp_tl[t >> 8][t & 255] = tlbuf[t];
-  }
-}
-extern "C" int plm_debug_pp_timeline(unsigned long long* host_out) {  // 2 x 256 entries
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_tl), sizeof(unsigned long long) * 512);
-}
-
-// =============================================================================================
 // launchers (called from the C ABI entry points in attn.hip when no document mask is given)
 // =============================================================================================
 void plm_attn_fwd_causal(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
   const dim3 grid((unsigned)(plm_cdiv(T, 256) * nh * B)), block(256);
-  hipLaunchKernelGGL((attn_fwd_causal_kernel<4>), grid, block, 0, s, qkv, out, lse, (int)T, (int)nh, plm_env().attn_map);
+  hipLaunchKernelGGL((attn_fwd_causal_kernel<4>), grid, block, 0, s, qkv, out, lse, (int)T, (int)nh);
 }
 void plm_attn_bwd_causal(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
                          const float* rs, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s) {
   const dim3 block(256);
-  // dQ first: it computes delta[b,h,q] for its queries and publishes it for the dK/dV kernel
-  const bool pp = plm_env().attn_pp != 0;
-  hipLaunchKernelGGL((attn_bwd_dq_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 256) * nh * B)), block, 0, s, qkv, out, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, pp ? -1.f : 1.f, plm_env().attn_map);
-  if (plm_env().attn_pp == 2)
-    hipLaunchKernelGGL((attn_bwd_dkdv_pp_kernel<7, true, true>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), dim3(512), 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, plm_env().attn_pp_prio, plm_env().attn_map);
-  else if (plm_env().attn_pp == 3)
-    hipLaunchKernelGGL((attn_bwd_dkdv_pp_kernel<7, false, false>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), dim3(512), 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, plm_env().attn_pp_prio, plm_env().attn_map);
-  else if (pp)
-    hipLaunchKernelGGL((attn_bwd_dkdv_pp_kernel<7, false, true>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), dim3(512), 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, plm_env().attn_pp_prio, plm_env().attn_map);
-  else
-    hipLaunchKernelGGL((attn_bwd_dkdv_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), block, 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, plm_env().attn_map);
+  // dQ first: it computes delta[b,h,q] for its queries and publishes -delta for the dK/dV kernel (which reads it straight into its dP accumulators)
+  hipLaunchKernelGGL((attn_bwd_dq_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 256) * nh * B)), block, 0, s, qkv, out, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, -1.f);
+  hipLaunchKernelGGL((attn_bwd_dkdv_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), block, 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh);
 }

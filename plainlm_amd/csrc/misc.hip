@@ -29,9 +29,6 @@ static void load_env() {
   g_env.nt_hybrid_min_k = num("PLM_NT_HYBRID_MIN_K");
   g_env.nt_duo = (int)num("PLM_NT_DUO");
   g_env.duo_stagger_us = getenv("PLM_DUO_STAGGER_US") ? atof(getenv("PLM_DUO_STAGGER_US")) : -1.0;
-  g_env.attn_map = getenv("PLM_ATTN_MAP") ? atoi(getenv("PLM_ATTN_MAP")) : 0;
-  g_env.attn_pp_prio = getenv("PLM_ATTN_PP_PRIO") ? atoi(getenv("PLM_ATTN_PP_PRIO")) : 0;
-  g_env.attn_pp = getenv("PLM_ATTN_PP") ? atoi(getenv("PLM_ATTN_PP")) : 0;
   g_env.duo_dbg = getenv("PLM_DUO_DBG") ? atoi(getenv("PLM_DUO_DBG")) : 0;
 }
 const PlmEnv& plm_env() {

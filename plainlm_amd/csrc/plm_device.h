@@ -41,9 +41,6 @@ struct PlmEnv {
   int nt_duo;                 // PLM_NT_DUO: unset / 0 = never the two-workgroups-per-CU 256x128 kernels (gemm_duo.hip); else a bit mask of the fused
                               // entry points that take them where the shape allows: 1 fc1 + SwiGLU, 2 dX fc2 + SwiGLU backward, 4 w_qkv + RoPE
   double duo_stagger_us;      // PLM_DUO_STAGGER_US: start offset of every CU's second workgroup (-1: from the K-loop length)
-  int attn_map;               // PLM_ATTN_MAP: block -> (row tile, head) order of the causal attention kernels: 0 tile-major, 1 XCD-aware head-major
-  int attn_pp_prio;           // PLM_ATTN_PP_PRIO: s_setprio experiment bits of the ping-pong kernel (1 matrix phase, 2 arithmetic phase, 4 waves 4-7 statically)
-  int attn_pp;                // PLM_ATTN_PP: causal attention backward takes the ping-pong dK/dV kernel (attn_causal.hip)
   int duo_dbg;                // PLM_DUO_DBG: timing-only ablation bits of gemm_duo.hip's SwiGLU-backward epilogue (results are garbage): 1 gate / up
                               // loads from cache-resident rows, 2 no stores, 4 stores to cache-resident rows, 8 no exp / rcp
 };
