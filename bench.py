@@ -228,6 +228,16 @@ def spawn_ranks(n):
   return rc
 
 
+def claim_stdout():
+  """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio when a communicator is created (it lands AFTER
+  Python's own output when stdout is a pipe: the C buffer is flushed at exit), and any other library may print as well - so this process's
+  fd 1 is pointed at stderr for its whole life, and the JSON line is written to the descriptor returned here."""
+  sys.stdout.flush()
+  keep = os.dup(1)
+  os.dup2(2, 1)
+  return keep
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -247,6 +257,7 @@ def main():
 
   if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     raise SystemExit(spawn_ranks(a.gpus))
+  json_fd = claim_stdout()
   rank = int(os.environ.get('RANK', 0))
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))
@@ -431,7 +442,7 @@ def main():
       out['cpu_baseline'] = cpu_baseline(c)
 
   if rank == 0:
-    print(json.dumps(out), flush=True)
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
   if world > 1:
     dist.barrier()
     dist.destroy_process_group()
