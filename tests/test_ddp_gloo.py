@@ -106,12 +106,22 @@ def _worker(rank, world, port, out_dir, tied=False):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize('tied', [False, True])
 def test_two_rank_bucketed_allreduce_equals_accumulation(tmp_path, tied):
-  world = 2
+  _bucketed_allreduce_equals_accumulation(tmp_path, 2, tied)
+
+
+@pytest.mark.timeout(600)
+def test_four_rank_bucketed_allreduce_equals_accumulation(tmp_path):
+  """The same contract at world_size 4 (the row split r::W, the mean over W x accum micro-batches, the agreement helpers)."""
+  _bucketed_allreduce_equals_accumulation(tmp_path, 4, False)
+
+
+def _bucketed_allreduce_equals_accumulation(tmp_path, world, tied):
   mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), tied), nprocs=world, join=True)
   r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
   # (ii) identical params and reduced grads on every rank
-  assert torch.equal(r[0]['params'], r[1]['params'])
-  assert torch.equal(r[0]['grads'], r[1]['grads'])
+  for i in range(1, world):
+    assert torch.equal(r[0]['params'], r[i]['params'])
+    assert torch.equal(r[0]['grads'], r[i]['grads'])
   # (i)+(iii) single process, accumulation over all W*accum micro-batches, one flat mean
   ocfg = O.OracleConfig(**CFG, tie_embeddings=tied)
   names = O.param_names(ocfg)
