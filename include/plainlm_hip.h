@@ -158,8 +158,8 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (BASE-2 log-sum-exp of the
  *               scaled scores, = LSE / ln 2: the form plm_attn_bwd's exp2 consumes; opaque to the caller otherwise).  No transposed / contiguous copies of q, k, v are made anywhere.
  * plm_attn_bwd: same rotated qkv; dqkv bf16[B*T, 3*nh*hd] = gradient w.r.t. the PRE-rotation q, k (the inverse
- *               rotation is applied in the kernels' epilogues) and v; delta fp32[B,nh,T] scratch (rowsum(dO * O), written by the dQ
- *               kernel and read by the dK/dV kernel that follows it).
+ *               rotation is applied in the kernels' epilogues) and v; delta fp32[B,nh,T] scratch (+-rowsum(dO * O), written by the dQ
+ *               kernel and read by the dK/dV kernel that follows it; the causal family stores it negated: opaque to the caller).
  * qkv, out, dout, dqkv and the RoPE tables must be 16-byte aligned (LDS-DMA sources, whole-row 16-byte epilogue stores); misaligned
  * pointers are refused with PLM_E_INVALID. */
 int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
