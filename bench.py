@@ -248,6 +248,7 @@ def main():
   ap.add_argument('--no-extras', action='store_true', help='skip the untimed roofline / full-step / cpu legs')
   ap.add_argument('--comm', default=None, choices=[None, 'rccl', 'torch'])
   ap.add_argument('--bucket-mb', type=float, default=64)
+  ap.add_argument('--no-autotune', action='store_true', help='data-parallel runs: time the default data plane only')
   ap.add_argument('--single-device', action='store_true',
                   help='plumbing check on a 1-GPU box: every rank uses cuda:0 and the gradient exchange runs over gloo (RCCL refuses '
                        'two ranks on one device); the printed rate is NOT a throughput measurement and says so')
@@ -285,18 +286,9 @@ def main():
   flat = model.enable_main_grad()
   params = list(model.parameters())
 
-  reducer = None
   force_reducer = world == 1 and os.environ.get('PLM_FORCE_REDUCER')  # one-GPU what-if: the whole DDP data plane with a 1-rank communicator
-  if world > 1 or force_reducer:
-    comm = ddp.make_comm(device, a.comm)
-    comm_tail = ddp.make_tail_comm(comm)
-    reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
-                              reserve_cus=ddp.COMM_CUS if force_reducer else None, writers=model.grad_writers(), comm_tail=comm_tail,
-                              groups=model.grad_groups())
-    reducer.broadcast_params([p.data for p in params])
-    model.sink.on_ready = reducer.param_ready
-    model.sink.on_queued = reducer.param_queued
-    model.sink.resolve_queue_budget(device, agreed=ddp.agree_min(model.sink.resolve_queue_budget(device)))
+  ddp_on = world > 1 or bool(force_reducer)
+  st = {'reducer': None}  # the gradient reducer of the step being timed (None: single GPU, no data plane)
 
   # synthetic tokens: rank r takes rows r, r+W, ... (DistributedSampler(shuffle=False) order)
   n_pool = 4
@@ -320,6 +312,7 @@ def main():
 
   def fwd_bwd(i, recast=True):
     ids, tgt, dstart = pool[i % n_pool]
+    reducer = st['reducer']
     model.sink.begin_window()
     if reducer is not None:
       reducer.begin(sync=True)
@@ -335,51 +328,167 @@ def main():
     if world > 1:
       dist.barrier()
 
-  for i in range(a.warmup):
-    fwd_bwd(i)
-  torch.cuda.synchronize()
-  barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for i in range(a.steps):
-    loss = fwd_bwd(i)
-  torch.cuda.synchronize()
-  barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    tt = torch.tensor([elapsed], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = tt.item()
-  last_loss = float(loss.item())
+  def timed(warmup, steps):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; returns (seconds = max over
+    ranks, per-rank seconds, last loss)."""
+    loss = None
+    for i in range(warmup):
+      loss = fwd_bwd(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+      loss = fwd_bwd(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    local = time.perf_counter() - t0
+    per_rank = [local]
+    if world > 1:
+      tt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+      dist.all_gather(tt, torch.tensor([local], dtype=torch.float64))
+      per_rank = [float(t.item()) for t in tt]
+    return max(per_rank), per_rank, float(loss.item())
 
-  ms_per_step = 1e3 * elapsed / a.steps
-  tokens_per_step = B * T * world
-  value = tokens_per_step / (elapsed / a.steps)
+  # ---- N = 1 reference inside the same run (data-parallel runs only): rank 0 alone, before any communicator exists, the others
+  # wait at the barrier - the scaling efficiency of this line does not depend on a second run on another box / another day
+  n1_ms = None
+  if ddp_on and not a.single_device:
+    if rank == 0:
+      for i in range(a.warmup):
+        fwd_bwd(i)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for i in range(a.steps):
+        fwd_bwd(i)
+      torch.cuda.synchronize()
+      n1_ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    barrier()
+
+  comms, alt_default = None, None
+  if ddp_on:
+    # the communicator set: uncapped root + children capped at 8 / 16 workgroups (ncclCommSplit with maxCTAs); the default data plane
+    # is ddp.pick_comms' (PLM_COMM_CUS = 16 for the buckets reduced during backward, the exposed tail bucket through the root)
+    comms = ddp.make_comm_set(device, a.comm, caps=sorted({8, 16, ddp.COMM_CUS} - {0}))
+    comm, comm_tail, reserve = ddp.pick_comms(comms)
+    alt_default = {'algo': os.environ.get('PLM_COMM_ALGO') or 'allreduce', 'cap': reserve, 'tail': comm_tail is not None}
+    reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
+                              reserve_cus=reserve, writers=model.grad_writers(), comm_tail=comm_tail, groups=model.grad_groups(),
+                              algo=alt_default['algo'])
+    reducer.broadcast_params([p.data for p in params])
+    model.sink.on_ready = reducer.param_ready
+    model.sink.on_queued = reducer.param_queued
+    model.sink.resolve_queue_budget(device, agreed=ddp.agree_min(model.sink.resolve_queue_budget(device)))
+    st['reducer'] = reducer
+
+  def apply_alt(alt):
+    c, t, r = ddp.pick_comms(comms, cap=alt['cap'], tail=alt['tail'])
+    st['reducer'].configure(comm=c, comm_tail=t, reserve_cus=r, algo=alt['algo'])
+
+  # ---- the timed region of the contract (for a data-parallel run: on the DEFAULT data plane)
+  elapsed, per_rank, last_loss = timed(a.warmup, a.steps)
   fpt = flops_per_token(c, hidden)
-  out = {
-    'metric': f'tokens/sec fwd+bwd ({a.config.upper()}, seq={T}, bf16)', 'value': round(value, 1), 'unit': 'tokens/s',
-    'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-    'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-    'config': {'workload': f'plainLM {a.config} decoder ({c["n_layers"]}L d={c["d_model"]} nh={c["n_heads"]} h={hidden} V={V}) '
-                           f'fwd+bwd incl. per-step weight casts' + (' + bucketed RCCL grad all-reduce' if world > 1 else '')
-                           + (', document-boundary masks (mean doc length 256)' if a.doc_mask else ''),
-               'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}'},
-    'tokens_per_sec_per_gpu': round(value / world, 1),
-    'mfu_bf16': round(value / world * fpt / (PEAK_BF16_TFLOPS * 1e12), 4),
-    'flops_per_token': fpt, 'loss': round(last_loss, 4),
-  }
-  if a.single_device:
-    out['data'] = 'synthetic; PLUMBING CHECK ONLY: all ranks share cuda:0, gradients over gloo - not a throughput measurement'
-  if reducer is not None:  # which data plane actually ran (make_comm may fall back from direct RCCL to torch's nccl backend)
-    out['comm'] = {'backend': reducer.comm.backend, 'ranks': reducer.comm.world_size, 'buckets': len(reducer.buckets),
-                   'bucket_cap_mb': a.bucket_mb, 'cu_reserve': reducer.reserve_cus,
-                   'reserve_policy': 'only inside a window of estimated GPU time behind each bucket launch (length: the bucket\'s collective in the previous step'
-                                     + (f', here modelled at {reducer.model_gbps} GB/s' if reducer.model_gbps else '') + ')',
-                   'bucket_ms': [round(1e3 * s, 3) for s in reducer.bucket_secs],
-                   'max_ctas_overlapped_buckets': getattr(reducer.comm, 'max_ctas', None),
-                   'tail_communicator': 'uncapped split' if reducer.comm_tail is not None else 'none (tail bucket on the same communicator)',
-                   'nccl_max_nchannels_env': os.environ.get('NCCL_MAX_NCHANNELS')}
+
+  def line(elapsed, last_loss):
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = B * T * world / (elapsed / a.steps)
+    o = {
+      'metric': f'tokens/sec fwd+bwd ({a.config.upper()}, seq={T}, bf16)', 'value': round(value, 1), 'unit': 'tokens/s',
+      'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+      'config': {'workload': f'plainLM {a.config} decoder ({c["n_layers"]}L d={c["d_model"]} nh={c["n_heads"]} h={hidden} V={V}) '
+                             f'fwd+bwd incl. per-step weight casts' + (' + bucketed RCCL grad all-reduce' if world > 1 else '')
+                             + (', document-boundary masks (mean doc length 256)' if a.doc_mask else ''),
+                 'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}'},
+      'tokens_per_sec_per_gpu': round(value / world, 1),
+      'mfu_bf16': round(value / world * fpt / (PEAK_BF16_TFLOPS * 1e12), 4),
+      'flops_per_token': fpt, 'loss': round(last_loss, 4),
+    }
+    if a.single_device:
+      o['data'] = 'synthetic; PLUMBING CHECK ONLY: all ranks share cuda:0, gradients over gloo - not a throughput measurement'
+    return o
+
+  def comm_info(alt, per_rank, extra=None):
+    reducer = st['reducer']
+    info = {'backend': reducer.comm.backend, 'ranks': reducer.comm.world_size, 'buckets': len(reducer.buckets),
+            'bucket_cap_mb': a.bucket_mb, 'selected': alt, 'cu_reserve': reducer.reserve_cus,
+            'reserve_policy': 'only inside a window of estimated GPU time behind each bucket launch; window = the bucket\'s measured collective, '
+                              'frozen + agreed over the ranks after %d steps (PLM_COMM_WINDOWS)' % ddp.FREEZE_AFTER
+                              + (f'; here modelled at {reducer.model_gbps} GB/s' if reducer.model_gbps else ''),
+            'max_ctas_overlapped_buckets': getattr(reducer.comm, 'max_ctas', None),
+            'tail_communicator': 'uncapped root' if reducer.comm_tail is not None else 'none (tail bucket on the same communicator)',
+            'nccl_max_nchannels_env': os.environ.get('NCCL_MAX_NCHANNELS'),
+            'rank_ms_per_step': {'min': round(1e3 * min(per_rank) / a.steps, 3), 'max': round(1e3 * max(per_rank) / a.steps, 3)},
+            'n1_ms_per_step': round(n1_ms, 3) if n1_ms is not None else None,
+            'n1_note': 'rank 0 alone (no data plane, same process, before any communicator existed), same warm-up / steps'}
+    info.update(reducer.stats())  # bucket_ms, exposed_comm_ms (the join wait of the last step), clock scale, share of MFMA launches that ran reserved
+    if extra:
+      info.update(extra)
+    return info
+
+  out = line(elapsed, last_loss)
+  if ddp_on:
+    if n1_ms is not None:
+      tt = torch.tensor([n1_ms], dtype=torch.float64)
+      if world > 1:
+        dist.broadcast(tt, src=0)
+      n1_ms = float(tt.item())
+    out['comm'] = comm_info(alt_default, per_rank)
+
+  # ---- data-parallel autotune (untimed): every alternative of {all-reduce, reduce-scatter + all-gather} x {no reserve, 8, 16 CUs}
+  # x {tail bucket on the capped communicator, on the uncapped root} for a few steps each; the ranks agree on the winner (the
+  # alternative whose SLOWEST rank is fastest); if it is not the default it is then timed over the full `steps`, and the better of
+  # the two full timed regions is the line's value (both are reported).  A watchdog prints the default's line if any of this hangs.
+  if ddp_on and not a.no_autotune and os.environ.get('PLM_BENCH_AUTOTUNE', '1') != '0':
+    import threading
+    deadline = float(os.environ.get('PLM_BENCH_AUTOTUNE_TIMEOUT', '300'))
+    def give_up():
+      out['comm']['autotune'] = f'did not finish within {deadline:.0f} s: this line is the default data plane\'s timed run'
+      if rank == 0:
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+      os._exit(0)
+    dog = threading.Timer(deadline, give_up)
+    dog.daemon = True
+    dog.start()
+    direct = isinstance(comms[0], ddp.RcclComm)
+    alts = []
+    for algo in (('allreduce', 'rsag') if direct else ('allreduce',)):
+      for cap in (0, 8, 16):
+        for tail in ((False, True) if (cap and cap in comms) else (False,)):
+          alts.append({'algo': algo, 'cap': cap, 'tail': tail})
+    if alt_default not in alts:
+      alts.insert(0, alt_default)
+    n_try = int(os.environ.get('PLM_BENCH_AUTOTUNE_STEPS', '4'))
+    local_ms = []
+    for alt in alts:
+      apply_alt(alt)
+      for i in range(2):
+        fwd_bwd(i)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for i in range(n_try):
+        fwd_bwd(i)
+      torch.cuda.synchronize()
+      local_ms.append(1e3 * (time.perf_counter() - t0) / n_try)
+    win, agreed = ddp.agree_winner(local_ms)
+    table = [dict(alt, ms_per_step=round(ms, 3)) for alt, ms in zip(alts, agreed)]
+    runs = [dict(alt_default, ms_per_step=out['ms_per_step'], role='default')]
+    chosen = alt_default
+    if alts[win] != alt_default and agreed[win] < 0.995 * agreed[alts.index(alt_default)]:
+      apply_alt(alts[win])
+      e2, pr2, l2 = timed(max(2, ddp.FREEZE_AFTER + 1), a.steps)
+      runs.append(dict(alts[win], ms_per_step=round(1e3 * e2 / a.steps, 3), role='autotune winner'))
+      if e2 < elapsed:
+        elapsed, per_rank, last_loss, chosen = e2, pr2, l2, alts[win]
+        out = line(elapsed, last_loss)
+    if chosen == alt_default:
+      apply_alt(alt_default)
+    out['comm'] = comm_info(chosen, per_rank, {'alternatives': table, 'timed_runs': runs,
+                                               'autotune': f'{len(alts)} alternatives x {n_try} steps (max over ranks, agreed); value = the better of the full timed runs'})
+    dog.cancel()
+  ms_per_step = out['ms_per_step']
+  reducer = st['reducer']
 
   if not a.no_extras:
     # ---- roofline leg: identical steps with HIP events around every MFMA kernel launch (untimed) ----
@@ -412,12 +521,13 @@ def main():
       import plainlm_amd as P
       from plainlm_amd.optim import FlatAdamW
       opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
-      if reducer is not None:
+      if reducer is not None:  # FlatAdamW has re-laid the gradient spans: a new bucket plan on the same (selected) data plane
         reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
                                   reserve_cus=reducer.reserve_cus, writers=model.grad_writers(), comm_tail=reducer.comm_tail,
-                                  groups=model.grad_groups())
+                                  groups=model.grad_groups(), algo=reducer.algo)
         model.sink.on_ready = reducer.param_ready
         model.sink.on_queued = reducer.param_queued
+        st['reducer'] = reducer
 
       def full(i):
         fwd_bwd(i, recast=not opt.emits_shadows)  # FlatAdamW writes the bf16 shadows of the weights it has just updated

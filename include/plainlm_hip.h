@@ -32,8 +32,7 @@ extern "C" {
 
 int plm_version(void);
 const char* plm_last_error_string(void);
-/* The library reads its environment switches (PLM_GEMM_V1, PLM_TN_NO_BIG, PLM_NT_NO_HYBRID, PLM_NT_HYBRID_MIN_K, PLM_NT_DUO,
- * PLM_DUO_STAGGER_US, PLM_DUO_DBG: tests and A/B
+/* The library reads its environment switches (PLM_GEMM_V1, PLM_TN_NO_BIG, PLM_NT_NO_HYBRID, PLM_NT_HYBRID_MIN_K: tests and A/B
  * runs; none is needed in production) ONCE, at its first call - no launch path calls getenv.  A process that changes one of them
  * afterwards (the test-suite does) calls this to have them read again. */
 void plm_reload_env(void);
@@ -111,9 +110,10 @@ int plm_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
                      int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, void* stream);
 /* same as plm_gemm_bf16_nt with an explicit kernel choice (autotuning / A-B measurements / tests):
  * variant 0 = automatic, 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA double-buffered,
- * 4 / 5 / 6 = persistent 256x256 / 256x192 / 256x128 with the deep-prefetch ring (half-tile slots refilled two K-tiles
- *             ahead) and offset wave groups - the kernels the automatic policy chooses from; 3 = 4 (kept for callers of round 1)
- * (3..6: bf16 C, no accumulate; 2..6: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
+ * 4 / 5 / 6 / 7 = persistent 256x256 / 256x192 / 256x128 / 128x192 with the deep-prefetch ring (half-tile slots refilled two
+ *             K-tiles ahead) and offset wave groups - the kernels the automatic policy chooses from (128x192, round 5: the short
+ *             batches, M = 8192 of config_doc_mask.yaml:35); 3 = 4 (kept for callers of round 1)
+ * (3..7: bf16 C, no accumulate; 2..7: K % 64 == 0, N % 8 == 0, ldc % 8 == 0). */
 int plm_gemm_bf16_nt_ex(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, int c_dtype, int accumulate, const float* alpha_dev, int variant,
                         void* stream);

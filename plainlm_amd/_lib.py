@@ -17,7 +17,7 @@ _lib = None
 
 # ABI the signatures below were written for (plm_version() of the library must match: a stale .so that still exports every
 # symbol but with other argument lists / struct layouts would corrupt memory instead of raising)
-EXPECTED_ABI = 105
+EXPECTED_ABI = 106
 
 _P = C.c_void_p
 _I64 = C.c_int64

@@ -81,8 +81,6 @@ static bool ensure_num_cus() {
   }
   return true;
 }
-// for gemm_duo.hip: one slot per CU outside the reserve (0 when the device cannot be queried)
-int plm_persistent_slots() { return ensure_num_cus() ? persistent_slots() : 0; }
 
 static double round_efficiency(int64_t tiles, int slots) {
   const int64_t rounds = (tiles + slots - 1) / slots;
@@ -144,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   static_assert(!(GLU || GLUB) || (BM == 256 && BN == 256 && WN == 4 && !HYB), "GLU epilogues: 256x256 tiles, whole-K items");
   static_assert(!(GLU && GLUB), "one epilogue at a time");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
-  static_assert(WM * WN == 8 && (TN == 64 || TN == 96) && (TM == 128 || TM == 64), "unsupported geometry");
+  static_assert(WM * WN == 8 && (TN == 64 || TN == 96) && (TM == 128 || TM == 64 || TM == 32), "unsupported geometry");
   constexpr int AH = TM / 2;                        // rows of one wave's A half
-  constexpr int AF = AH / 32;                       // 32-row MFMA fragments per A half
+  constexpr int NA = AH / 16;                       // 16-row MFMA blocks per A half (= 32-row pieces of the wave tile: TM / 32)
   // A wave's B columns split into "half" 0 = its first BF0 32-column fragments and half 1 = its last fragment
   // (TN = 64: 1 + 1; TN = 96: 2 + 1 - the 256x192 tile, whose phases 1 and 4 carry twice the MFMAs of 2 and 3).
   constexpr int BF0 = TN / 32 - 1, NBF = BF0 + 1;
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // The C stores of an epilogue (NS per wave when the tile is interior) are YOUNGER than the loads the first
   // K-tile of the next tile waits for; counting them in lets them drain under that K-tile's MFMAs instead of in front
   // of them (vmcnt retires in order, so a plain count would wait for every store).
-  constexpr int NS = 2 * AF * 2 * NBF * (GLUB ? 2 : 1) + (GLU ? 2 * AF * 2 : 0);
+  constexpr int NS = NA * 2 * NBF * (GLUB ? 2 : 1) + (GLU ? NA * 2 : 0);
   static_assert(D_P1 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
@@ -346,9 +344,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     int m0 = 0, n0 = 0, kbeg = 0, kend = K, split = -1;
     if (HYB) take(cc, m0, n0, kbeg, kend, split);
     const int nk = HYB ? (kend - kbeg) / 64 : nkt;
-    f32x4_t acc4[4 * AF][2 * NBF];  // [16-row block of the wave's 2 * AH rows][16-column block of its TN columns]
+    f32x4_t acc4[2 * NA][2 * NBF];  // [16-row block of the wave's 2 * AH rows][16-column block of its TN columns]
 #pragma unroll
-    for (int i = 0; i < 4 * AF; ++i)
+    for (int i = 0; i < 2 * NA; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * NBF; ++j)
 #pragma unroll
@@ -359,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       // again (a few KiB of L2 hits per workgroup), so the DMA issue and the counted waits of the loop carry no conditionals;
       // the loads are drained before the kernel ends.
       const char* cur = smem + st * STAGE;
-      bf16x8_t a6[2 * AF][2], b06[2 * BF0][2], b16[2][2];  // fragments: [16-row block][K-step of 32]
+      bf16x8_t a6[NA][2], b06[2 * BF0][2], b16[2][2];  // fragments: [16-row block][K-step of 32]
       // end of a phase: counted wait for the half-tile the next phase reads (+ the previous epilogue's stores while they are
       // still counted), then the workgroup barrier
       auto end_phase = [&](auto wtag) {
@@ -377,13 +375,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int j = 0; j < 2 * BF0; ++j) b06[j][ks] = frag16(cur + OFF_B0, wn * BF0 * 32 + j * 16 + l15, ks);
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = frag16(cur + OFF_A0, wm * AH + f * 16 + l15, ks);
+        for (int f = 0; f < NA; ++f) a6[f][ks] = frag16(cur + OFF_A0, wm * AH + f * 16 + l15, ks);
       }
       if (grp1) end_phase(integral_constant<int, D_P1>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int j = 0; j < 2 * BF0; ++j) acc4[f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[f][j]);
       if (!grp1) end_phase(integral_constant<int, D_P1>{});
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[f][2 * BF0 + c]);
       if (!grp1) end_phase(integral_constant<int, D_P2>{});
@@ -408,23 +406,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = frag16(cur + OFF_A1, wm * AH + f * 16 + l15, ks);
+        for (int f = 0; f < NA; ++f) a6[f][ks] = frag16(cur + OFF_A1, wm * AH + f * 16 + l15, ks);
       if (grp1) end_phase(integral_constant<int, D_P4 - B1_DMA>{});  // B1'' is only issued in phase 4
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[2 * AF + f][2 * BF0 + c]);
+          for (int c = 0; c < 2; ++c) acc4[NA + f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[NA + f][2 * BF0 + c]);
 
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage B1
       issue_b(1, smem + s_st * STAGE, s_k);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
-          for (int j = 0; j < 2 * BF0; ++j) acc4[2 * AF + f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[2 * AF + f][j]);
+          for (int j = 0; j < 2 * BF0; ++j) acc4[NA + f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[NA + f][j]);
       if (!grp1) end_phase(integral_constant<int, D_P4>{});
       credit = false;
       credit_i = 0;
@@ -437,8 +435,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       const int mrem = M - rfull * BM;
       float* slab = hyb.slabs + ((int64_t)split * mrem - (int64_t)rfull * BM) * N;
 #pragma unroll
-      for (int f = 0; f < 4 * AF; ++f) {  // 16-row block f of the wave: A half f / (2 AF), block f % (2 AF) inside it
-        const int gm = m0 + wm * TM + (f / (2 * AF)) * AH + (f % (2 * AF)) * 16 + l15;
+      for (int f = 0; f < 2 * NA; ++f) {  // 16-row block f of the wave tile (A half f / NA, block f % NA inside it: rows f * 16 ...)
+        const int gm = m0 + wm * TM + f * 16 + l15;
         if (gm >= M) continue;
 #pragma unroll
         for (int j = 0; j < 2 * NBF; ++j) {
@@ -454,13 +452,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     // was passed (x * 1.0f is exact, so the bits do not depend on which way the branch goes)
     if (alpha_dev != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 4 * AF; ++i)
+      for (int i = 0; i < 2 * NA; ++i)
 #pragma unroll
         for (int j = 0; j < 2 * NBF; ++j) acc4[i][j] *= alpha;
     }
 #pragma unroll
-    for (int mf = 0; mf < 2 * AF; ++mf) {
-      const int mrow0 = m0 + wm * TM + (mf / AF) * AH + (mf % AF) * 32;
+    for (int mf = 0; mf < NA; ++mf) {  // 32-row pieces = the 16-row blocks 2 mf, 2 mf + 1 of acc4 (block f holds rows f * 16 ... of the wave tile)
+      const int mrow0 = m0 + wm * TM + mf * 32;
       if (GLUB) {
         // SwiGLU backward on this 32 x 64 piece of d(act): lane (l15, q) holds, per 16 x 16 block (sr, bq, sc), row sr*16 + l15 and
         // hidden units bq*32 + sc*16 + 4 q .. + 3 of the wave's 64
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int sr = 0; sr < 2; ++sr) {  // 16 rows at a time: d(gate) in scratch rows 0-15, d(up) in rows 16-31
           const int gm_l = min(mrow0 + sr * 16 + l15, M - 1);
-          const int fi = (mf / AF) * 2 * AF + (mf % AF) * 2 + sr;
+          const int fi = 2 * mf + sr;
 #pragma unroll
           for (int bq = 0; bq < 2; ++bq)
 #pragma unroll
@@ -518,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
             for (int sc = 0; sc < 2; ++sc) {  // 16-column half of the 32-column block: this lane holds columns 4 q .. 4 q + 3 of it
               bf16x4_t o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc4[(mf / AF) * 2 * AF + (mf % AF) * 2 + sr][bh * 2 + sc][e]);
+              for (int e = 0; e < 4; ++e) o[e] = f2bf(acc4[2 * mf + sr][bh * 2 + sc][e]);
               const int row = sr * 16 + l15, c = bq * 4 + sc * 2 + (q >> 1);
               *reinterpret_cast<bf16x4_t*>(epi + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = o;
             }
@@ -549,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
         for (int sr = 0; sr < 2; ++sr)
 #pragma unroll
           for (int sc = 0; sc < 2; ++sc) {
-            const int fi = (mf / AF) * 2 * AF + (mf % AF) * 2 + sr;
+            const int fi = 2 * mf + sr;
             bf16x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = plm_swiglu_bf16(f2bf(acc4[fi][sc][e]), f2bf(acc4[fi][2 + sc][e]));
@@ -626,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
                                                              const float* __restrict__ alpha_dev, int tiles_m, int tiles_n, TnGroup grp,
                                                              TnGroupOut gout) {
   constexpr int BM = 256, BN = 256, WN = 4;
-  constexpr int TM = 128, TN = 64, AH = 64, AF = 2;
+  constexpr int TM = 128, TN = 64, AH = 64, AF = 2, NA = 2 * AF;
   constexpr int HT = 64 * 256;  // one half-tile: 64 k-rows x 128 cols bf16
   constexpr int STAGE = 4 * HT;
   constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT;
@@ -807,7 +805,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
     }
     f32x4_t acc4[4 * AF][4];  // [16-row block of the wave's 128 rows][16-column block of its 64 columns]
 #pragma unroll
-    for (int i = 0; i < 4 * AF; ++i)
+    for (int i = 0; i < 2 * NA; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -830,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int c = 0; c < 2; ++c) b06[c][ks] = tr_frag16(cur + OFF_B0, wn * 32 + c * 16, ks);
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = tr_frag16(cur + OFF_A0, wm * AH + f * 16, ks);
+        for (int f = 0; f < NA; ++f) a6[f][ks] = tr_frag16(cur + OFF_A0, wm * AH + f * 16, ks);
       }
       auto sync = [&](auto wtag) {
         if (more) wait_vm<decltype(wtag)::value>(); else wait_vm<0>();
@@ -841,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[f][c] = mfma16(a6[f][ks], b06[c][ks], acc4[f][c]);
       if (!grp1) sync(WAll{});
@@ -857,7 +855,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[f][2 + c]);
       if (!grp1) sync(WAll{});
@@ -868,14 +866,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f) a6[f][ks] = tr_frag16(cur + OFF_A1, wm * AH + f * 16, ks);
+        for (int f = 0; f < NA; ++f) a6[f][ks] = tr_frag16(cur + OFF_A1, wm * AH + f * 16, ks);
       if (grp1) sync(std::integral_constant<int, W_ALL - 2>{});  // the fourth DMA group of this K-tile is only issued in phase 4
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc4[2 * AF + f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[2 * AF + f][2 + c]);
+          for (int c = 0; c < 2; ++c) acc4[NA + f][2 + c] = mfma16(a6[f][ks], b16[c][ks], acc4[NA + f][2 + c]);
 
       if (more) {
         issue(s_bp, pb[1], s_ldb, sst + OFF_B1, s_k);
@@ -883,9 +881,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int f = 0; f < 2 * AF; ++f)
+        for (int f = 0; f < NA; ++f)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc4[2 * AF + f][c] = mfma16(a6[f][ks], b06[c][ks], acc4[2 * AF + f][c]);
+          for (int c = 0; c < 2; ++c) acc4[NA + f][c] = mfma16(a6[f][ks], b06[c][ks], acc4[NA + f][c]);
       if (!grp1) {
         if (more) wait_vm<W_ALL>(); else wait_vm<0>();
         phase_barrier();
@@ -1160,6 +1158,45 @@ __global__ __launch_bounds__(256) void nt_streamk_reduce_kernel(const float* __r
   }
 }
 
+// Tile shapes of the persistent NT kernel and the automatic policy that picks one per launch: round efficiency of the tile count on the
+// persistent grid x the useful fraction of the (ragged) edge tiles x a measured per-tile rate relative to 256x256.  256x192 has 22 % fewer
+// LDS-DMA bytes and 17 % fewer LDS reads per MFMA than 256x128, and N = 768 is four 192-column tiles = exactly two rounds at M = 32768;
+// 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape.  128x192 (round 5; 8 waves of 32x96) is the shape of the
+// short batches: M = 8192 (the reference's document-mask config, config_doc_mask.yaml:35) makes N = 768 exactly ONE round of 256 tiles
+// and N = 2304 exactly three, where every 256-row tile leaves 25-62 % of the chip idle.
+// Order = preference on ties (the first strictly greater wins).
+struct NtTileShape {
+  int bm, bn;
+  double rate;
+};
+static const NtTileShape kNtTiles[4] = {{256, 256, 1.0}, {256, 128, 0.88}, {256, 192, 0.94}, {128, 192, 0.80}};
+static const int kNtTileVariant[4] = {4, 6, 5, 7};  // the explicit variant number of each (plm_gemm_bf16_nt_ex)
+static double nt_tile_eff(int i, int64_t M, int64_t N, int slots) {
+  const NtTileShape& t = kNtTiles[i];
+  const int64_t tm = plm_cdiv(M, t.bm), tn = plm_cdiv(N, t.bn);
+  return round_efficiency(tm * tn, slots) * ((double)N / (double)(tn * t.bn)) * ((double)M / (double)(tm * t.bm)) * t.rate;
+}
+// index into kNtTiles of the best shape, its efficiency in *eff
+static int nt_pick_tile(int64_t M, int64_t N, int slots, double* eff) {
+  int best = 0;
+  double be = -1.0;
+  for (int i = 0; i < 4; ++i) {
+    const double e = nt_tile_eff(i, M, N, slots);
+    if (e > be) {
+      be = e;
+      best = i;
+    }
+  }
+  *eff = be;
+  return best;
+}
+// the hardware-scheduled 128x128 LDS-DMA kernel of gemm.hip (two 4-wave workgroups per CU, ~0.8 of the persistent 256x256 per-tile rate)
+// on the same scale: what the persistent kernels have to beat
+static double nt_dma128_eff(int64_t M, int64_t N, int slots) {
+  const int64_t tm = plm_cdiv(M, 128), tn = plm_cdiv(N, 128);
+  return round_efficiency(tm * tn, 2 * slots) * ((double)N / (double)(tn * 128)) * ((double)M / (double)(tm * 128)) * 0.80;
+}
+
 // Hybrid plan for the 256x256 NT kernel: whole-K tiles for the full rounds, stream-K over the remaining tile rows.
 // Returns false when the plain schedules are at least as good (or the shape does not qualify).
 struct NtHybridPlan {
@@ -1185,10 +1222,9 @@ bool plm_nt_hybrid_plan(int64_t M, int64_t N, int64_t K, NtHybridPlan* p) {
   if (round_efficiency(tiles, slots) >= 0.9) return false;  // plain 256x256 is already well packed
   // ... or a narrower plain tile is (lm_head dX on the whole chip: 4 x 192 columns = exactly two rounds; in the step that beats the
   // hybrid's slab traffic by 0.5 % end to end, round 2).  The same per-tile rates as the automatic policy below.
-  const int64_t c192 = plm_cdiv(N, 192), c128 = plm_cdiv(N, 128);
-  const double e192 = round_efficiency(R * c192, slots) * ((double)N / (c192 * 192.0)) * 0.94;
-  const double e128 = round_efficiency(R * c128, slots) * ((double)N / (c128 * 128.0)) * 0.88;
-  if (!mk && (e192 >= 0.9 || e128 >= 0.9)) return false;
+  double e_plain;
+  nt_pick_tile(M, N, slots, &e_plain);
+  if (!mk && e_plain >= 0.9) return false;
   const int64_t rf = ((tiles / slots) * slots) / Cn;        // whole tile rows inside the full rounds
   const int64_t rem = (R - rf) * Cn;
   if (rem <= 0 || rf <= 0) return false;
@@ -1217,11 +1253,6 @@ static bool aligned16(std::initializer_list<const void*> ptrs) {
   return (v & 15) == 0;
 }
 
-// gemm_duo.hip: two 4-wave workgroups per CU on 256x128 tiles; epi 0 plain | 1 SwiGLU forward | 2 SwiGLU backward | 3 RoPE
-bool plm_launch_gemm_nt_duo(int epi, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
-                            int64_t N, int64_t K, const float* alpha_dev, uint16_t* act, int64_t ldact, const float* rcos,
-                            const float* rsin, int64_t T, int64_t rope_cols, hipStream_t s);
-
 // fc1 + SwiGLU in one launch (see GLU above).  Returns false when the shape does not qualify (the caller then runs the GEMM and
 // plm_swiglu_fwd separately - same bits).
 bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc, uint16_t* act,
@@ -1232,7 +1263,6 @@ bool plm_launch_gemm_nt_glu(const uint16_t* A, int64_t lda, const uint16_t* B, i
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (plm_env().nt_duo > 0 && (plm_env().nt_duo & 1) && plm_launch_gemm_nt_duo(1, A, lda, B, ldb, C, ldc, M, N, K, nullptr, act, ldact, nullptr, nullptr, 0, 0, s)) return true;
   if (K % 64 != 0 || N % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldact % 8 != 0) return false;
   if (!aligned16({A, B, C, act})) return false;
   const int tm = (int)plm_cdiv(M, 256), tn = (int)(N / 256);
@@ -1253,9 +1283,6 @@ bool plm_launch_gemm_nt_glub(const uint16_t* A, int64_t lda, const uint16_t* B, 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (plm_env().nt_duo > 0 && (plm_env().nt_duo & 2) &&
-      plm_launch_gemm_nt_duo(2, A, lda, B, ldb, DU, lddu, M, h, K, nullptr, const_cast<uint16_t*>(U), ldu, nullptr, nullptr, 0, 0, s))
-    return true;
   if (K % 64 != 0 || h % 256 != 0 || M < 512 || lda % 8 != 0 || ldb % 8 != 0 || ldu % 4 != 0 || lddu % 8 != 0) return false;
   if (!aligned16({A, B, DU}) || (reinterpret_cast<uintptr_t>(U) & 7) != 0) return false;  // U is read in 8-byte pieces
   const int tm = (int)plm_cdiv(M, 256), tn = (int)(h / 256);
@@ -1276,18 +1303,14 @@ bool plm_launch_gemm_nt_rope(const uint16_t* A, int64_t lda, const uint16_t* B, 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (plm_env().nt_duo > 0 && (plm_env().nt_duo & 4) && plm_launch_gemm_nt_duo(3, A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, rcos, rsin, T, rope_cols, s)) return true;
   if (K % 64 != 0 || N % 8 != 0 || M < 512 || N < 128 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
   if (!aligned16({A, B, C, rcos, rsin})) return false;
-  const int tm = (int)plm_cdiv(M, 256);
-  const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
   const int slots = persistent_slots();
-  const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
-  const double e192 = round_efficiency((int64_t)tm * tn192, slots) * ((double)N / (tn192 * 192.0)) * 0.94;
-  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.88;
-  if (e256 < 0.85 && e192 < 0.85 && e128 < 0.85) return false;  // badly quantised (CU reserve): the caller takes GEMM + rope pass
-  const int which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
-  const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
+  double eff;
+  const int which = nt_pick_tile(M, N, slots, &eff);
+  // badly quantised on every tile shape (odd CU reserves): the caller takes the plain GEMM (which may prefer the 128x128 kernel) + the rope pass
+  if (eff < nt_dma128_eff(M, N, slots)) return false;
+  const int tm = (int)plm_cdiv(M, kNtTiles[which].bm), tn_ = (int)plm_cdiv(N, kNtTiles[which].bn);
   const int nt_ = tm * tn_;
   const dim3 g(nt_ < slots ? nt_ : slots), block(512);
   const HybridArgs hyb{tm, 0, 1, nullptr};
@@ -1296,45 +1319,34 @@ bool plm_launch_gemm_nt_rope(const uint16_t* A, int64_t lda, const uint16_t* B, 
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
                        nullptr, tm, tn_, hyb, ea);
   else if (which == 1)
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
+                       nullptr, tm, tn_, hyb, ea);
+  else if (which == 2)
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
                        nullptr, tm, tn_, hyb, ea);
   else
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
+    hipLaunchKernelGGL((gemm_nt_big_kernel<128, 192, 4, 2, false, false, false, true>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
                        nullptr, tm, tn_, hyb, ea);
   return true;
 }
 
 // Host-side launcher used by plm_gemm_bf16_nt (gemm.hip). Returns false when no big-tile variant fits.
 
-// variant: 0 automatic | 4 / 5 / 6 the persistent kernel on 256x256 / 256x192 / 256x128 tiles (what the automatic policy picks from;
-// explicit numbers exist for the tests and tools/kbench.py) | 3 = 4.
+// variant: 0 automatic | 4 / 5 / 6 / 7 the persistent kernel on 256x256 / 256x192 / 256x128 / 128x192 tiles (what the automatic policy picks
+// from; explicit numbers exist for the tests and tools/kbench.py) | 3 = 4.
 // Returns false when the shape is better served by the 128x128 kernels of gemm.hip.
 bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, const float* alpha_dev, void* workspace, size_t workspace_bytes,
                             hipStream_t s) {
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  if (variant == 7) return plm_launch_gemm_nt_duo(0, A, lda, B, ldb, C, ldc, M, N, K, alpha_dev, nullptr, 0, nullptr, nullptr, 0, 0, s);
-  const int tm = (int)plm_cdiv(M, 256);
-  const int tn256 = (int)plm_cdiv(N, 256), tn128 = (int)plm_cdiv(N, 128), tn192 = (int)plm_cdiv(N, 192);
+  if (!ensure_num_cus()) return false;
   const int slots = persistent_slots();
-  // tile shape = round efficiency on the persistent grid x a measured per-tile rate (1 / 0.94 / 0.88): 256x192 has 22 % fewer
-  // LDS-DMA bytes and 17 % fewer LDS reads per MFMA than 256x128, and N = 768 is four 192-column tiles = exactly two rounds at
-  // M = 32768; 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape
-  const double e256 = round_efficiency((int64_t)tm * tn256, slots) * ((double)N / (tn256 * 256.0));
-  const double e192 = round_efficiency((int64_t)tm * tn192, slots) * ((double)N / (tn192 * 192.0)) * 0.94;
-  const double e128 = round_efficiency((int64_t)tm * tn128, slots) * ((double)N / (tn128 * 128.0)) * 0.88;
   const dim3 block(512);
-  const HybridArgs hyb{tm, 0, 1, nullptr};  // plain schedule
   // long K with a badly quantised tile count (lm_head dX: 384 tiles on 256 CUs): whole-K tiles for the full rounds + stream-K
   // over the remaining tile rows, on the staggered schedule (needs the caller's fp32 workspace)
   if (variant == 0 && workspace) {
     NtHybridPlan p;
     if (plm_nt_hybrid_plan(M, N, K, &p)) {
+      const int tm = (int)plm_cdiv(M, 256), tn256 = (int)plm_cdiv(N, 256);
       const int64_t rem_rows = M - (int64_t)p.rfull * 256;
       const size_t need = (size_t)p.nslabs * (size_t)rem_rows * (size_t)N * sizeof(float);
       if (workspace_bytes >= need) {
@@ -1352,20 +1364,29 @@ bool plm_launch_gemm_nt_big(int variant, const uint16_t* A, int64_t lda, const u
       }
     }
   }
-  // below ~0.85 round efficiency (e.g. 240 slots when CUs are reserved for RCCL) the hardware-scheduled 128x128 LDS-DMA
-  // kernel (~0.9 of the persistent kernels' per-tile rate, no round quantisation) is the better choice
-  if (variant == 0 && (M < 512 || N < 128 || (e256 < 0.85 && e128 < 0.85))) return false;
-  // one schedule (deep-prefetch 4-phase ring with offset wave groups), three tile shapes; variant 3 is kept as an alias of 4
-  int which = variant <= 4 ? 0 : variant - 4;  // 0: 256x256, 1: 256x192, 2: 256x128
-  if (variant == 0) which = (e192 > e256 && e192 > e128) ? 1 : (e256 >= e128 ? 0 : 2);
-  const int tn_ = which == 0 ? tn256 : which == 1 ? tn192 : tn128;
+  // one schedule (deep-prefetch 4-phase ring with offset wave groups), four tile shapes; variant 3 is kept as an alias of 4
+  int which = 0;
+  if (variant == 0) {
+    double eff;
+    which = nt_pick_tile(M, N, slots, &eff);
+    // when every persistent shape quantises badly (e.g. odd slot counts while CUs are reserved for RCCL) the hardware-scheduled 128x128
+    // LDS-DMA kernel is the better choice
+    if (M < 512 || N < 128 || eff < nt_dma128_eff(M, N, slots)) return false;
+  } else {
+    for (int i = 0; i < 4; ++i)
+      if (kNtTileVariant[i] == (variant == 3 ? 4 : variant)) which = i;
+  }
+  const int tm = (int)plm_cdiv(M, kNtTiles[which].bm), tn_ = (int)plm_cdiv(N, kNtTiles[which].bn);
   const int nt_ = tm * tn_;
   const dim3 g(nt_ < slots ? nt_ : slots);
+  const HybridArgs hyb{tm, 0, 1, nullptr};  // plain schedule
   if (which == 0)
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 256, 2, 4>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
   else if (which == 1)
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
+  else if (which == 2)
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
   else
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 128, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
+    hipLaunchKernelGGL((gemm_nt_big_kernel<128, 192, 4, 2>), g, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha_dev, tm, tn_, hyb, EpiArgs{});
   return true;
 }

@@ -38,11 +38,6 @@ struct PlmEnv {
   bool tn_no_big;             // PLM_TN_NO_BIG: no persistent 256x256 TN kernel
   bool nt_no_hybrid;          // PLM_NT_NO_HYBRID: no whole-K + stream-K NT schedule
   long long nt_hybrid_min_k;  // PLM_NT_HYBRID_MIN_K: lowers the hybrid schedule's thresholds (-1: defaults)
-  int nt_duo;                 // PLM_NT_DUO: unset / 0 = never the two-workgroups-per-CU 256x128 kernels (gemm_duo.hip); else a bit mask of the fused
-                              // entry points that take them where the shape allows: 1 fc1 + SwiGLU, 2 dX fc2 + SwiGLU backward, 4 w_qkv + RoPE
-  double duo_stagger_us;      // PLM_DUO_STAGGER_US: start offset of every CU's second workgroup (-1: from the K-loop length)
-  int duo_dbg;                // PLM_DUO_DBG: timing-only ablation bits of gemm_duo.hip's SwiGLU-backward epilogue (results are garbage): 1 gate / up
-                              // loads from cache-resident rows, 2 no stores, 4 stores to cache-resident rows, 8 no exp / rcp
 };
 const PlmEnv& plm_env();
 

@@ -23,21 +23,30 @@ from . import _lib
 # CUs kept free for RCCL's kernels while a gradient bucket's collective is running, and the matching cap on RCCL channels (one
 # workgroup each; 0 = no reserve and RCCL's own channel count).  The persistent GEMMs launch one workgroup per CU; a workgroup that
 # finds its CU taken by a collective would run after the others (a second round), so the GEMM grids shrink by this many while - and
-# only while - an all-reduce is expected to be in flight (GradReducer: a window of estimated GPU time behind every bucket launch,
-# its length the bucket's measured duration in the previous step); the forward pass, the lm_head backward and every GEMM behind a
-# finished collective keep all 256 CUs.  Sizing: 649 MB of fp32 gradients per ~20 ms of backward is 32 GB/s of algorithm bandwidth
-# = 57 GB/s of bus bandwidth at 8 ranks; one RCCL channel moves 15-25 GB/s over an xGMI link, so 8 channels cover it twice over.
-# The reserve costs the GEMMs it applies to ~1 % per 4 CUs (profiles/r04_ddp_whatif.txt).
-COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '8'))
-# Estimated rates (flop/s) by kernel family, for the reducer's clock of enqueued GPU time (bench.py's roofline families, round 3)
+# only while - an all-reduce is expected to be in flight (GradReducer: a window of estimated GPU time behind every bucket launch);
+# the forward pass, the lm_head backward and every GEMM behind a finished collective keep all 256 CUs.  Sizing: 649 MB of fp32
+# gradients per ~20 ms of backward is 32 GB/s of algorithm bandwidth = 57 GB/s of bus bandwidth at 8 ranks; one RCCL channel moves
+# 15-25 GB/s over an xGMI link.  The SIZE of the reserve hardly matters to the GEMMs (4 vs 16 CUs: 0.1-0.2 ms per step,
+# profiles/r04_ddp_whatif.txt), so until a multi-GPU run has compared them the default stays at the generous 16 (round 4 had
+# lowered it to 8 on a back-of-envelope figure) - and bench.py measures {0, 8, 16} itself when it runs on more than one
+# GPU (autotune, below).
+COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
+# Prior rates (flop/s) by kernel family for the reducer's clock of enqueued GPU time.  They only fix the RATIOS between families:
+# the clock is rescaled every step by measured / estimated time of the previous step (HIP events around begin() ... finish()), so a
+# slower or faster box, or the 420M shapes, do not drift the windows away from the collectives they follow.
 _FAMILY_RATE = {'gemm_nt': 1.15e15, 'gemm_nt_fused': 0.85e15, 'gemm_tn': 1.15e15, 'attn_fwd': 0.55e15, 'attn_bwd': 0.36e15}
-# The cap is set twice for world > 1: PER COMMUNICATOR (ncclConfig_t.maxCTAs through plm_comm_init_capped) and, before the first
-# RCCL call of the process, as NCCL_MAX_NCHANNELS (unless the caller has set it) - the per-communicator form has only ever run with ONE
-# rank (tests/test_model_gpu.py::test_rccl_capped_communicator_and_split_tail_single_rank), and the environment variable is also
-# the only knob of the torch.distributed fallback.  PLM_COMM_TAIL=1 (opt-in until a multi-GPU run has been recorded) adds an
-# UNCAPPED communicator split off the capped one for the tail bucket (embed_tokens: ready when backward has ended, nothing
-# left to overlap with), so that the exposed 154 MB all-reduce may use every channel - it needs NCCL_MAX_NCHANNELS left unset by us,
-# which PLM_COMM_TAIL=1 therefore does.
+# How the reserve windows get their lengths (PLM_COMM_WINDOWS):
+#   'frozen' (default) - a bucket's window is its collective's measured duration (HIP events on the side stream, EMA over the first
+#            FREEZE_AFTER communicating steps), then the ranks agree on the maximum over ranks once (control plane) and the table - and
+#            the clock scale - never change again: from that step on every rank takes the same GEMM plans in every step.
+#   'model'  - bytes / PLM_COMM_MODEL_GBPS (implied when that variable is set): no measurement at all; the only mode in which a
+#            data-parallel run is bit-reproducible RUN TO RUN (the plans - stream-K / split-K partitions - depend on the windows).
+#   'ema'    - round 4's behaviour: follow the previous step's measurement forever (plans may change from step to step).
+FREEZE_AFTER = 3
+# The caps are per communicator (ncclConfig_t.maxCTAs through plm_comm_split); NCCL_MAX_NCHANNELS is never set by this package
+# (round 4 exported it process-wide as belt and braces, which also throttled the exposed tail bucket).  The communicator
+# used for buckets that are reduced when backward has ended (embed_tokens: nothing left to overlap with) is the UNCAPPED root
+# communicator (PLM_COMM_TAIL=0 sends them through the capped one).
 
 
 class RcclComm:
@@ -82,10 +91,11 @@ class RcclComm:
     _lib.check(self.lib.plm_comm_split(self.handle, C.byref(child), int(max_ctas)), 'plm_comm_split')
     return RcclComm(self.rank, self.world_size, self.device_index, max_ctas=max_ctas, _handle=child)
 
-  def allreduce_avg_(self, span, stream):
-    # PLM_COMM_ALGO=rsag: the mean as reduce-scatter + all-gather in place (one-hop collectives over all xGMI links) instead of RCCL's
-    # own all-reduce; opt-in until a multi-GPU run has compared the two
-    fn, name = ((self.lib.plm_comm_rsag_avg_f32, 'plm_comm_rsag_avg_f32') if os.environ.get('PLM_COMM_ALGO') == 'rsag' else
+  def allreduce_avg_(self, span, stream, algo=None):
+    # algo 'rsag': the mean as reduce-scatter + all-gather in place (one-hop collectives over all xGMI links) instead of RCCL's own
+    # all-reduce (PLM_COMM_ALGO is the default when the caller does not say; bench.py's autotune measures both)
+    algo = algo or os.environ.get('PLM_COMM_ALGO') or 'allreduce'
+    fn, name = ((self.lib.plm_comm_rsag_avg_f32, 'plm_comm_rsag_avg_f32') if algo == 'rsag' else
                 (self.lib.plm_comm_allreduce_avg_f32, 'plm_comm_allreduce_avg_f32'))
     _lib.check(fn(self.handle, C.c_void_p(span.data_ptr()), span.numel(), C.c_void_p(stream.cuda_stream)), name)
 
@@ -108,7 +118,7 @@ class TorchDistComm:
     self.world_size = dist.get_world_size(group)
     self.backend = 'torch-' + dist.get_backend(group)
 
-  def allreduce_avg_(self, span, stream=None):
+  def allreduce_avg_(self, span, stream=None, algo=None):  # algo: RCCL-direct only
     if dist.get_backend(self.group) == 'gloo':  # gloo has no AVG
       dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group)
       span.div_(self.world_size)
@@ -177,18 +187,22 @@ class GradReducer:
   """
 
   def __init__(self, flat_grad, params, spans, comm, bucket_cap_mb=64, overlap=True, force=False, reserve_cus=None,
-               writers=None, comm_tail=None, groups=None):
+               writers=None, comm_tail=None, groups=None, algo=None, ctl_group=None):
     """groups: see plan_buckets (Transformer.grad_groups()).
     writers: optional {id(param): n} = how many backward kernels write that parameter's gradient per backward pass
     (default 1).  A weight shared by lm_head and embed_tokens (tie_embeddings, models/transformer.py:131-132) has two: the
     head's dW first, the embedding scatter last.  A bucket is launched only when every writer of every member has
-    reported; launching after the first would let RCCL reduce the span in place while the second kernel still adds to it."""
+    reported; launching after the first would let RCCL reduce the span in place while the second kernel still adds to it.
+    algo: 'allreduce' | 'rsag' (None: PLM_COMM_ALGO, else all-reduce).  ctl_group: control-plane process group for the one-off
+    agreement on the window table (None: the default group)."""
     self.flat = flat_grad
     self.comm = comm
     # Buckets that become ready when backward has ended (nothing left to hide them behind) go through comm_tail when one is
     # given (see COMM_CUS): the bucket of params[0] - embed_tokens, whose gradient is the last kernel of backward - and
     # whatever finish() still has to launch.
     self.comm_tail = comm_tail
+    self.algo = algo
+    self.ctl_group = ctl_group
     self.buckets = plan_buckets(spans, int(bucket_cap_mb * (1 << 20)), groups)
     self.numel = [n for _, n in spans]
     self.index_of = {id(p): i for i, p in enumerate(params)}
@@ -209,25 +223,77 @@ class GradReducer:
     self.launched = []
     # CUs left to the collectives while one is expected to be running (see COMM_CUS).  The host enqueues kernels milliseconds ahead
     # of the GPU, so "is a collective running when THIS GEMM starts" is answered on a clock of estimated GPU time: every MFMA launch
-    # advances it by flops / its family's rate (ops.LAUNCH_HOOK), a bucket launch opens a window [now or the end of the previous
-    # window, + the bucket's duration], and a launch inside a window shrinks its grid.  A bucket's duration is what its collective
-    # took in the previous step (HIP events on the side stream), before the first measurement bytes / PLM_COMM_MODEL_GBPS (also the
-    # way to ask "what if the links gave X GB/s" on one GPU, where the measured collectives are local copies).
+    # advances it by flops / its family's rate x a learned scale (ops.LAUNCH_HOOK), a bucket launch opens a window [now or the end of
+    # the previous window, + the bucket's duration], and a launch inside a window shrinks its grid.  Window lengths: see
+    # PLM_COMM_WINDOWS above.
     if reserve_cus is None:
       reserve_cus = COMM_CUS if (self.on_gpu and comm.world_size > 1) else 0
     self.reserve_cus = int(reserve_cus) if self.on_gpu else 0
     self._reserved = False
     model_gbps = os.environ.get('PLM_COMM_MODEL_GBPS')
     self.model_gbps = float(model_gbps) if model_gbps else None
-    gbps = self.model_gbps or 60.0
-    self.bucket_secs = [(hi - lo) * 4 / (gbps * 1e9) for lo, hi, _ in self.buckets]
-    self._timing = {}  # bucket -> (start event, end event) of its last collective
-    self.clock, self.window_end = 0.0, -1.0
+    self.window_mode = 'model' if self.model_gbps else os.environ.get('PLM_COMM_WINDOWS', 'frozen')
+    if self.window_mode not in ('model', 'frozen', 'ema'):
+      raise ValueError(f"PLM_COMM_WINDOWS={self.window_mode!r}: expected 'frozen', 'model' or 'ema'")
+    self._bucket_bytes = [(hi - lo) * 4 for lo, hi, _ in self.buckets]
+    self.reset_windows()
     # the dW queue (functional.GradSink) is flushed at bucket boundaries once it holds this many bytes of gradients
     self.dw_group_bytes = int(float(os.environ.get('PLM_DW_GROUP_MB', '80')) * 1e6)
     self._queued, self._queued_per_bucket, self._queued_bytes = set(), {}, 0
+    self._exposed = None  # (event before, event after) the join of the last communicating step
+    self.n_mfma_launches = self.n_reserved_launches = 0
+
+  def reset_windows(self):
+    """Forget what was learned about the collectives' durations and the clock (a different communicator / algorithm / cap)."""
+    gbps = self.model_gbps or 60.0
+    self.bucket_secs = [nb / (gbps * 1e9) for nb in self._bucket_bytes]
+    self._timing = {}          # bucket -> (start event, end event) of its last collective
+    self._span = None          # (event at begin(), event at finish(), estimated clock at finish()) of the last communicating step
+    self.rate_scale = 1.0      # measured / estimated GPU time from begin() to finish(): rescales _FAMILY_RATE
+    self.sync_steps = 0
+    self.frozen = self.window_mode == 'model'
+    self.clock, self.window_end = 0.0, -1.0
+
+  def configure(self, comm=None, comm_tail=False, reserve_cus=None, algo=None):
+    """Switch the data plane between two steps (bench.py's autotune): any of the communicator used while backward runs, the one
+    for the tail buckets (None = the same), the CU reserve and the algorithm; what had been learned about durations is dropped."""
+    if self.sync:
+      raise RuntimeError('GradReducer.configure: inside a step (between begin() and finish())')
+    if comm is not None:
+      self.comm = comm
+    if comm_tail is not False:
+      self.comm_tail = comm_tail
+    if reserve_cus is not None:
+      self.reserve_cus = int(reserve_cus) if self.on_gpu else 0
+    if algo is not None:
+      self.algo = algo
+    self.reset_windows()
+
+  def _learn(self):
+    """Top of a communicating step: fold the previous step's measurements (finished: finish() joined the streams and the caller has
+    run a whole forward since... or not - unfinished events are skipped) into the window table and the clock scale; in 'frozen'
+    mode agree on them across the ranks after FREEZE_AFTER steps and stop."""
+    if self.frozen:
+      return
+    for b, (s, e) in list(self._timing.items()):
+      if e.query():
+        # clamped to bytes / 400 GB/s ... bytes / 10 GB/s: a collective measured while a rank was late (or a 1-rank local copy) must
+        # not switch the reserve off for good or hold it for the whole of backward
+        secs = min(max(s.elapsed_time(e) * 1e-3, self._bucket_bytes[b] / 400e9), self._bucket_bytes[b] / 10e9)
+        self.bucket_secs[b] = 0.5 * self.bucket_secs[b] + 0.5 * secs
+    if self._span is not None:
+      t0, t1, est = self._span
+      if t1.query() and est > 0:
+        scale = self.rate_scale * (t0.elapsed_time(t1) * 1e-3) / est  # est was computed WITH the current scale
+        self.rate_scale = min(max(0.5 * self.rate_scale + 0.5 * scale, 0.25), 4.0)
+    if self.window_mode == 'frozen' and self.sync_steps >= FREEZE_AFTER:
+      vals = agree_max_floats(self.bucket_secs + [self.rate_scale], self.ctl_group)
+      self.bucket_secs, self.rate_scale = vals[:-1], vals[-1]
+      self.frozen = True
 
   def begin(self, sync):
+    if self.on_gpu and (self._reserved or self.sync):
+      self.abort()  # a step that raised between begin() and finish() left the hook / the reserve behind
     self.sync = bool(sync) and (self.comm.world_size > 1 or self.force)
     self.pending = [sum(self.writers[i] for i in idxs) for (_, _, idxs) in self.buckets]
     self.reports = [0] * len(self.writers)
@@ -235,13 +301,28 @@ class GradReducer:
     self._queued, self._queued_per_bucket, self._queued_bytes = set(), {}, 0
     self.clock, self.window_end = 0.0, -1.0
     if self.on_gpu and self.sync:
-      if self.model_gbps is None:
-        for b, (s, e) in list(self._timing.items()):  # last step's collectives (finished: finish() joined the streams)
-          if e.query():
-            self.bucket_secs[b] = 0.5 * self.bucket_secs[b] + 0.5 * s.elapsed_time(e) * 1e-3
+      self._learn()
+      self.sync_steps += 1
       if self.reserve_cus:
         from . import ops
         ops.LAUNCH_HOOK = self._on_launch
+        if not self.frozen:
+          t0 = torch.cuda.Event(enable_timing=True)
+          t0.record()
+          self._span_begin = t0
+
+  def abort(self):
+    """Drop the launch hook and the CU reserve (a step raised between begin() and finish(): 'Train loss is nan', out of memory);
+    engine.step calls this from its exception path, begin() as a safety net.  Collectives already enqueued are joined."""
+    from . import ops
+    if self.on_gpu:
+      if ops.LAUNCH_HOOK == self._on_launch:
+        ops.LAUNCH_HOOK = None
+      if self._reserved:
+        ops.set_cu_reserve(0)
+        self._reserved = False
+      torch.cuda.current_stream().wait_stream(self.stream)
+    self.sync = False
 
   def _on_launch(self, family, flops):
     """ops.LAUNCH_HOOK: called right before an MFMA kernel is enqueued."""
@@ -250,7 +331,18 @@ class GradReducer:
       from . import ops
       ops.set_cu_reserve(self.reserve_cus if want else 0)
       self._reserved = want
-    self.clock += flops / _FAMILY_RATE.get(family, 1.0e15)
+    self.n_mfma_launches += 1
+    self.n_reserved_launches += int(want)
+    self.clock += self.rate_scale * flops / _FAMILY_RATE.get(family, 1.0e15)
+
+  def stats(self):
+    """What the windows are doing (bench.py prints it; ADVICE r04: nothing used to show whether the reserve was ever on)."""
+    exposed = None
+    if self._exposed is not None and self._exposed[1].query():
+      exposed = round(self._exposed[0].elapsed_time(self._exposed[1]), 3)
+    return {'window_mode': self.window_mode, 'frozen': self.frozen, 'bucket_ms': [round(1e3 * v, 3) for v in self.bucket_secs],
+            'clock_scale': round(self.rate_scale, 3), 'exposed_comm_ms': exposed,
+            'reserved_launch_frac': round(self.n_reserved_launches / max(1, self.n_mfma_launches), 3)}
 
   def param_queued(self, p):
     """functional.GradSink.on_queued: the weight gradient of p has been queued for a grouped dW launch.  True = launch the group
@@ -279,13 +371,13 @@ class GradReducer:
       with torch.cuda.stream(self.stream):
         t0, t1 = self._timing.get(b) or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         t0.record(self.stream)
-        comm.allreduce_avg_(span, self.stream)
+        comm.allreduce_avg_(span, self.stream, self.algo)
         t1.record(self.stream)
         self._timing[b] = (t0, t1)
       # GEMMs enqueued inside this window may run beside the collective (see __init__)
       self.window_end = max(self.window_end, self.clock) + self.bucket_secs[b]
     else:
-      comm.allreduce_avg_(span, None)
+      comm.allreduce_avg_(span, None, self.algo)
     self.launched.append(b)
 
   def param_ready(self, p):
@@ -315,11 +407,18 @@ class GradReducer:
       if b not in self.launched:
         self._launch(b, tail=True)
     if self.on_gpu:
-      torch.cuda.current_stream().wait_stream(self.stream)
-    if self.on_gpu:
       from . import ops
+      cur = torch.cuda.current_stream()
+      # the join, bracketed by events: what the compute stream waits here is the EXPOSED part of the step's communication
+      e0, e1 = self._exposed or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+      e0.record(cur)
+      cur.wait_stream(self.stream)
+      e1.record(cur)
+      self._exposed = (e0, e1)
       if ops.LAUNCH_HOOK == self._on_launch:
         ops.LAUNCH_HOOK = None
+        if not self.frozen and getattr(self, '_span_begin', None) is not None:
+          self._span = (self._span_begin, e0, self.clock)  # measured vs estimated GPU time of this step's kernels
       if self._reserved:  # everything enqueued after the join runs with no collective in flight
         ops.set_cu_reserve(0)
         self._reserved = False
@@ -340,63 +439,68 @@ class GradReducer:
         self.comm.broadcast_(t.view(-1), 0, None)
 
 
-def make_comm(device, backend=None, group=None):
-  """Pick the data-plane backend.  On GPU the default is direct RCCL through the C ABI."""
+def make_comm_set(device, backend=None, group=None, caps=None):
+  """The data-plane communicators of a run: {0: uncapped root, cap: split of the root limited to `cap` workgroups, ...}.
+  On GPU the default is direct RCCL through the C ABI: the root is a plain ncclCommInitRank (the most travelled path of the
+  library), every capped communicator is an ncclCommSplit of it with ncclConfig_t.maxCTAs.  Collective; every decision that can
+  differ between ranks (a failed creation) is agreed on the control plane, so the ranks always end up with the same set.
+  backend 'torch' (or a failed direct set-up): {0: TorchDistComm} - torch.distributed has no per-communicator cap, the GEMM-side
+  reserve is then the only knob."""
+  caps = [COMM_CUS] if caps is None else list(caps)
   world = dist.get_world_size(group) if dist.is_initialized() else 1
   rank = dist.get_rank(group) if dist.is_initialized() else 0
   backend = backend or os.environ.get('PLM_COMM', 'rccl' if torch.device(device).type == 'cuda' else 'torch')
-  if backend == 'rccl':
-    idx = torch.device(device).index
-    idx = torch.cuda.current_device() if idx is None else idx
+  if backend != 'rccl':
+    if not dist.is_initialized():
+      raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")
+    return {0: TorchDistComm(group)}
+  idx = torch.device(device).index
+  idx = torch.cuda.current_device() if idx is None else idx
+  root, err = None, None
+  try:
+    root = RcclComm(rank, world, idx, store_group=group, max_ctas=0)
+  except Exception as e:  # noqa: BLE001 - reported below, on every rank
+    err = e
+  if not all_ranks_ok(err is None, group):
+    if root is not None:
+      root.close()
     if world == 1:
-      return RcclComm(rank, world, idx, store_group=group)
-    # The direct communicator is created collectively; if it fails on ANY rank every rank falls back to torch.distributed's
-    # nccl (= RCCL) backend, so that a box whose RCCL set-up differs from the build machine still trains.
-    # Process-wide belt and braces for the per-communicator cap (ncclConfig_t.maxCTAs has only ever run with one rank): ONLY with a
-    # positive cap (0 = RCCL's default channel count; RCCL clamps NCCL_MAX_NCHANNELS=0 to ONE channel), only when the user has not set it,
-    # and not when an uncapped tail communicator is wanted.  It also caps every other RCCL communicator of the process, and has
-    # no effect once RCCL has read its environment - both said out loud.
-    if COMM_CUS > 0 and os.environ.get('PLM_COMM_TAIL', '0') != '1' and 'NCCL_MAX_NCHANNELS' not in os.environ:
-      os.environ['NCCL_MAX_NCHANNELS'] = str(COMM_CUS)
-      late = dist.is_initialized() and dist.get_backend(group) == 'nccl'
-      if rank == 0:
-        print(f'[plainlm_amd.ddp] NCCL_MAX_NCHANNELS={COMM_CUS} set for this process (PLM_COMM_CUS; caps every RCCL communicator created '
-              f'from now on)' + ('; torch.distributed\'s nccl backend is already initialised: RCCL may have read its environment, the '
-                                 'per-communicator maxCTAs is then the only cap' if late else ''), flush=True)
-    comm, err = None, None
+      raise err
+    # if the direct communicator fails on ANY rank every rank falls back to torch.distributed's nccl (= RCCL) backend, so that a
+    # box whose RCCL set-up differs from the build machine still trains
+    print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl', flush=True)
+    return {0: TorchDistComm(dist.new_group(backend='nccl'))}
+  comms = {0: root}
+  for cap in sorted({int(c) for c in caps if int(c) > 0}):
+    child, err = None, None
     try:
-      comm = RcclComm(rank, world, idx, store_group=group)
-    except Exception as e:  # noqa: BLE001 - reported below, on every rank
+      child = root.split(max_ctas=cap)
+    except RuntimeError as e:
       err = e
     if all_ranks_ok(err is None, group):
-      return comm
-    if comm is not None:
-      comm.close()
-    print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl '
-          f'(NCCL_MAX_NCHANNELS={os.environ.get("NCCL_MAX_NCHANNELS")})', flush=True)
-    return TorchDistComm(dist.new_group(backend='nccl'))
-  if not dist.is_initialized():
-    raise RuntimeError("backend 'torch' needs torch.distributed to be initialised")
-  return TorchDistComm(group)
+      comms[cap] = child
+    else:
+      if child is not None:
+        child.close()
+      print(f'[plainlm_amd.ddp] rank {rank}: no communicator capped at {cap} workgroups ({err}); that cap is not available', flush=True)
+  return comms
 
 
-def make_tail_comm(comm, group=None):
-  """Uncapped communicator for the buckets that are reduced after backward has ended (see COMM_CUS), split off the capped
-  one; None when the data plane is not direct RCCL, the capped one is not capped, PLM_COMM_TAIL is not 1 (opt-in), or the split fails on
-  any rank (every rank then keeps using `comm` alone - agreed collectively)."""
-  if not isinstance(comm, RcclComm) or comm.max_ctas <= 0 or os.environ.get('PLM_COMM_TAIL', '0') != '1':
-    return None
-  tail, err = None, None
-  try:
-    tail = comm.split(max_ctas=0)
-  except RuntimeError as e:
-    err = e
-  if all_ranks_ok(err is None, group):
-    return tail
-  if tail is not None:
-    tail.close()
-  print(f'[plainlm_amd.ddp] rank {comm.rank}: no uncapped tail communicator ({err}); the tail bucket uses the capped one', flush=True)
-  return None
+def pick_comms(comms, cap=None, tail=None):
+  """(communicator for the buckets reduced while backward runs, communicator for the tail buckets or None, CU reserve) out of a
+  make_comm_set: the cap asked for (default COMM_CUS) when the set has it, else the uncapped root with the same GEMM-side reserve;
+  tail (default: PLM_COMM_TAIL != 0) sends the buckets that are reduced after backward through the uncapped root."""
+  cap = COMM_CUS if cap is None else int(cap)
+  tail = (os.environ.get('PLM_COMM_TAIL', '1') != '0') if tail is None else bool(tail)
+  comm = comms.get(cap, comms[0])
+  comm_tail = comms[0] if (tail and comm is not comms[0]) else None
+  return comm, comm_tail, max(cap, 0)
+
+
+def make_comm(device, backend=None, group=None):
+  """Engine entry point: (comm, comm_tail) with the default cap and tail policy."""
+  comm, comm_tail, _ = pick_comms(make_comm_set(device, backend, group))
+  return comm, comm_tail
 
 
 def agree_min(value, group=None):
@@ -417,3 +521,22 @@ def all_ranks_ok(ok, group=None):
   flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
   dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
   return bool(flag.item())
+
+
+def agree_max_floats(values, group=None):
+  """Elementwise maximum of a list of floats over the ranks (control plane; the values themselves without a process group)."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return [float(v) for v in values]
+  dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+  t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+  return [float(v) for v in t.tolist()]
+
+
+def agree_winner(local_ms, group=None):
+  """Autotune consensus: every rank passes its own timing of each alternative (same order on all ranks); the time of an alternative is
+  the SLOWEST rank's (that is the step time of a data-parallel job), the winner the smallest of those, ties to the lowest index.
+  Returns (index, agreed timings) - identical on every rank whatever the local timings were."""
+  agreed = agree_max_floats(local_ms, group)
+  best = min(range(len(agreed)), key=lambda i: (agreed[i], i))
+  return best, agreed

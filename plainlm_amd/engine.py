@@ -211,9 +211,11 @@ class HipEngine(torch.nn.Module):
 
     self.reducer = None
     if dist.is_initialized() and dist.get_world_size() > 1:
-      comm = ddp.make_comm(device, comm_backend)
+      # uncapped root communicator + a child capped at PLM_COMM_CUS workgroups for the buckets reduced while backward runs; the tail
+      # bucket (embed_tokens, ready when backward has ended) goes through the root
+      comm, comm_tail, reserve = ddp.pick_comms(ddp.make_comm_set(device, comm_backend))
       self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb,
-                                      writers=self.model.grad_writers(), comm_tail=ddp.make_tail_comm(comm),
+                                      writers=self.model.grad_writers(), comm_tail=comm_tail, reserve_cus=reserve,
                                       groups=self.model.grad_groups())
       self.reducer.broadcast_params([p.data for p in self.params])  # DDP ctor's _sync_module_states
       self.model.invalidate_shadows()
@@ -239,11 +241,16 @@ class HipEngine(torch.nn.Module):
     if self.reducer is not None:
       self.reducer.begin(sync=last)
 
-    loss = self.model.loss(inputs, targets, doc_start)
-    loss_val = loss.detach()
-    self._submit_nan_flag(loss_val)
-    self.check_losses(keep=self.nan_check_lag)
-    (loss / self.accumulation_steps).backward()
+    try:
+      loss = self.model.loss(inputs, targets, doc_start)
+      loss_val = loss.detach()
+      self._submit_nan_flag(loss_val)
+      self.check_losses(keep=self.nan_check_lag)
+      (loss / self.accumulation_steps).backward()
+    except BaseException:
+      if self.reducer is not None:  # 'Train loss is nan', out of memory: the launch hook and the CU reserve must not outlive the step
+        self.reducer.abort()
+      raise
     if self.reducer is not None:
       self.reducer.finish()
 

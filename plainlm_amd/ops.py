@@ -277,7 +277,7 @@ def _tn_workspace(nbytes, device):
 def gemm_nt(A, B, out=None, out_dtype=BF16, accumulate=False, alpha=None, variant=0):
   """C[M,N] = alpha * A[M,K] @ B[N,K]^T ; A, B bf16 (row stride may exceed K).
   variant: 0 auto | 1 128x128 register-staged | 2 128x128 LDS-DMA | 3 persistent 256x256, plain 4-phase ring |
-  4 / 5 / 6 persistent 256x256 / 256x192 / 256x128, deep-prefetch ring with offset wave groups (what auto picks from)."""
+  4 / 5 / 6 / 7 persistent 256x256 / 256x192 / 256x128 / 128x192, deep-prefetch ring with offset wave groups (what auto picks from)."""
   for t, n in ((A, 'A'), (B, 'B')):
     if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
       raise ValueError(f'gemm_nt.{n}: need a 2-D bf16 GPU tensor with unit inner stride')
@@ -356,11 +356,11 @@ def gemm_tn_grouped(problems):
     Ms[i], Ns[i] = M, N
     arr[i] = _lib.TnProblem(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, int(bool(accumulate)), _p(alpha))
   lib = _lib.load()
+  if lib.plm_gemm_tn_grouped_workspace_bytes(Ms, Ns, n, K) == 0:  # unsupported shapes (independent of the CU reserve): the caller's
+    return False                                                  # per-problem gemm_tn calls report to the launch hook themselves
   flops = sum(2.0 * a.shape[1] * b.shape[1] * K for a, b, *_ in problems)
-  _hook('gemm_tn', flops)
+  _hook('gemm_tn', flops)  # may change the CU reserve: the plan is taken after it
   nbytes = lib.plm_gemm_tn_grouped_workspace_bytes(Ms, Ns, n, K)
-  if nbytes == 0:
-    return False
   ws = _tn_workspace(nbytes, problems[0][0].device)
   with _Timed('gemm_tn', flops):
     _lib.check(lib.plm_gemm_bf16_tn_grouped(arr, n, K, _p(ws), nbytes, _stream()), 'plm_gemm_bf16_tn_grouped')

@@ -42,7 +42,8 @@ def _worker(rank, world, port, out_dir, tied=False):
   flat_p = torch.cat([params[n].reshape(-1) for n in names])
   flat_g = torch.zeros(off)
   plist = [flat_p[o:o + k] for o, k in spans]
-  comm = ddp.make_comm('cpu', 'torch')
+  comm, comm_tail = ddp.make_comm('cpu', 'torch')
+  assert comm_tail is None  # torch.distributed has no per-communicator cap: one communicator for everything
   # tied embeddings: the shared weight (parameter 0) is written twice per backward - lm_head's dW first, the embedding
   # scatter last (functional.HeadLossFn / EmbedFn) - and its bucket may only go out after the second write
   writers = {id(plist[0]): 2} if tied else None
@@ -57,7 +58,7 @@ def _worker(rank, world, port, out_dir, tied=False):
   calls = {'n': 0}
   orig = comm.allreduce_avg_
 
-  def counting(span, stream=None):
+  def counting(span, stream=None, algo=None):
     calls['n'] += 1
     return orig(span, stream)
 
@@ -98,6 +99,16 @@ def _worker(rank, world, port, out_dir, tied=False):
   # collective agreement used by make_comm's RCCL -> torch fallback: one failing rank makes every rank fall back
   assert ddp.all_ranks_ok(True) is True
   assert ddp.all_ranks_ok(rank != 1) is False
+  # autotune consensus (bench.py, world > 1): the ranks time the alternatives differently - rank r finds alternative r fastest - and
+  # must still pick the SAME winner: the alternative whose slowest rank is fastest (ties: lowest index)
+  local = [5.0, 5.0, 5.0, 4.0 + 0.01 * rank, 9.0]
+  local[rank % 3] = 1.0
+  win, agreed = ddp.agree_winner(local)
+  assert win == 3 and agreed[3] == pytest.approx(4.0 + 0.01 * (world - 1)) and agreed[4] == 9.0, (win, agreed)
+  win, agreed = ddp.agree_winner([2.0 + rank, 2.0 + (world - 1 - rank), 7.0])
+  assert win == 0 and agreed[:2] == [2.0 + world - 1] * 2  # a tie goes to the lowest index on every rank
+  # the one-off agreement on the reserve windows ('frozen' mode): the maximum over the ranks, elementwise
+  assert ddp.agree_max_floats([0.001 * (rank + 1), 1.0 - 0.1 * rank]) == pytest.approx([0.001 * world, 1.0])
   torch.save({'params': flat_p.clone(), 'grads': flat_g.clone()}, os.path.join(out_dir, f'r{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()

@@ -195,3 +195,77 @@ def test_bench_two_ranks_on_one_device():
   assert out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
   assert 'PLUMBING CHECK ONLY' in out['data']
   assert out['value'] > 0 and np.isfinite(out['loss']) and 10.0 < out['loss'] < 12.0  # ln(50280) = 10.83 at init
+
+
+_DDP_WRAPPER_SCRIPT = r'''
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+root, golden = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[3], RANK='0', WORLD_SIZE='1')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)  # torch_utils.py:16: the reference hard-codes 'nccl' (= RCCL on ROCm)
+import plainlm_amd as P
+z = np.load(os.path.join(golden, 'model.npz'))
+mdl = {k: torch.from_numpy(z[k]) for k in z.files}
+m = P.Transformer(P.ModelConfig(vocab_size=256, seq_len=64, dim=128, expand=8 / 3, n_layers=2, n_heads=2, mlp='glu'))
+m.load_state_dict({k[2:]: v for k, v in mdl.items() if k.startswith('w:')})
+m = m.cuda()
+from torch.nn.parallel import DistributedDataParallel as DDP
+model = DDP(m, device_ids=[0])  # engine/engine.py:64-65
+crit = torch.nn.CrossEntropyLoss()
+tok = mdl['tokens']
+ids, tgt = tok[:, :64].cuda(), tok[:, 1:65].reshape(-1).cuda()
+out = {}
+def relmax(a, ref):
+  a, ref = a.double().cpu(), ref.double().cpu()
+  return ((a - ref).abs().max() / ref.abs().max()).item()
+# two accumulation micro-steps: the first with gradient sync switched off (engine.py:104-105), the second syncing
+model.require_backward_grad_sync = False
+logits = model(ids, None)
+loss = crit(logits.float().view(-1, 256), tgt)
+(loss / 2).backward()
+out['loss0'] = loss.item()
+model.require_backward_grad_sync = True
+logits = model(ids, None)
+loss = crit(logits.float().view(-1, 256), tgt)
+(loss / 2).backward()
+out['loss1'] = loss.item()
+out['ref'] = mdl['loss'].item()
+out['grads'] = {n: relmax(p.grad, mdl['g:' + n]) for n, p in m.named_parameters()}
+out['so'] = [l.split()[-1] for l in open('/proc/self/maps') if 'libplainlm_hip' in l][:1]
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RESULT ' + json.dumps(out))
+'''
+
+
+@pytest.mark.timeout(600)
+def test_reference_style_path_under_torch_ddp_wrapper(tmp_path):
+  """Path B of INTEGRATION.md under its REAL wrapper (SURVEY section 8b: the module 'must survive being wrapped by DDP'):
+  a world-1 `nccl` (= RCCL) process group, `DistributedDataParallel(construct_model(...)[0], device_ids=[0])` as in
+  engine/engine.py:64-65, the reference's logits -> CrossEntropyLoss -> backward (engine.py:109-120) over two accumulation
+  micro-steps, the first with `require_backward_grad_sync = False` (engine.py:104-105) - DDP's reducer hooks our autograd
+  Functions' .grad outputs.  Accumulated gradients (2 x 1/2) against the reference's golden vectors.  Own process: a process group
+  inside the pytest process would leak into the reducer tests."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = tmp_path / 'ddp_wrapper.py'
+  script.write_text(_DDP_WRAPPER_SCRIPT)
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+  r = subprocess.run([sys.executable, str(script), root, GOLDEN, str(_free_port())], env=env, capture_output=True, text=True, timeout=540)
+  assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+  out = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
+  assert out['so'], 'the wrapped module did not run on libplainlm_hip.so'
+  for k in ('loss0', 'loss1'):
+    assert abs(out[k] - out['ref']) <= 1e-4 * abs(out['ref']), out
+  assert len(out['grads']) == 15
+  for n, v in out['grads'].items():
+    assert v < 4e-2, (n, v)

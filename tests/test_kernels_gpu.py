@@ -275,7 +275,7 @@ def test_gemm_nt(ops, M, N, K):
   close(acc, 1 + 0.5 * ref, 2e-5 * math.sqrt(K), 'gemm_nt accumulate/alpha')
 
 
-@pytest.mark.parametrize('variant', [2, 3, 4, 5, 6, 7])  # 128x128 LDS-DMA, the plain 256x256 ring, the three tiles of the automatic policy's deep ring, two workgroups per CU on 256x128 (gemm_duo.hip)
+@pytest.mark.parametrize('variant', [2, 3, 4, 5, 6, 7])  # 128x128 LDS-DMA, the plain 256x256 ring, the four tile shapes of the automatic policy's deep ring (256x256, 256x192, 256x128, 128x192)
 @pytest.mark.parametrize('M,N,K', [(512, 512, 64), (1000, 392, 192), (2048, 768, 768), (8192, 2304, 128), (300, 136, 64),
                                    (33000, 768, 64), (32768, 768, 2304)])
 def test_gemm_nt_variants(ops, M, N, K, variant):
@@ -454,41 +454,37 @@ def test_fc2_dx_swiglu_bwd_fused_epilogue(ops, M, h, K):
   assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(dy, w2t), u))
 
 
-@pytest.mark.parametrize('stagger', ['0', '3', None])
-def test_duo_kernels_fused_epilogues(ops, plm_env, stagger):
-  """The two-workgroups-per-CU 256x128 kernel family (gemm_duo.hip, PLM_NT_DUO=7: all three entry points) behind the three fused entry points: the bits
-  of GEMM + stand-alone kernel, for tile counts below / at / above the 512 resident workgroups, ragged M, with the second
-  workgroup of every CU started late (the default), 3 us late, and not late at all (a timing knob must not change a bit);
-  plus the plain kernel (variant 7) against the persistent 256x256 one on exactly-representable inputs."""
-  plm_env('PLM_NT_DUO', '7')
-  if stagger is not None:
-    plm_env('PLM_DUO_STAGGER_US', stagger)
-  g = torch.Generator(device='cuda').manual_seed(77)
-  for M, h, K in ((2048, 2048, 768), (32768, 2048, 768), (5000, 640, 256), (16384, 2816, 1024)):
-    x = bf(torch.randn(M, K, generator=g, device='cuda'))
-    w1 = bf(0.05 * torch.randn(2 * h, K, generator=g, device='cuda'))
-    u, act = ops.fc1_swiglu(x, w1)
-    u_ref = ops.gemm_nt(x, w1, variant=4)
-    assert torch.equal(u, u_ref), (M, h, K)
-    assert torch.equal(act, ops.swiglu_fwd(u_ref)), (M, h, K)
-    w2t = bf(0.05 * torch.randn(h, K, generator=g, device='cuda'))
-    uu = bf(torch.randn(M, 2 * h, generator=g, device='cuda'))
-    du = ops.fc2_dx_swiglu_bwd(x, w2t, uu)
-    assert torch.equal(du, ops.swiglu_bwd(ops.gemm_nt(x, w2t, variant=4), uu)), (M, h, K)
-    del x, w1, u, act, u_ref, w2t, uu, du
-  for B, T, nh, K in ((8, 1024, 12, 768), (32, 1024, 12, 768), (5, 200, 2, 128), (8, 2048, 16, 1024)):
-    d = nh * 64
-    x = bf(torch.randn(B * T, K, generator=g, device='cuda'))
-    w = bf(0.1 * torch.randn(3 * d, K, generator=g, device='cuda'))
-    cos, sin = (t.cuda() for t in O.rope_table(64, T))
-    got = ops.qkv_rope(x, w, cos, sin, B, T, nh)
-    two = ops.gemm_nt(x, w, variant=4) if B * T >= 512 else ops.gemm_nt(x, w)
-    ops.rope_qk_(two, cos, sin, B, T, nh)
-    assert torch.equal(got, two), (B, T, nh, K)
-  for M, N, K in ((32768, 768, 768), (4096, 2304, 64), (33000, 1032, 1024)):
+def test_short_batch_tile_128x192(ops):
+  """Round 5: the 128x192 tile of the persistent NT kernel (variant 7; 8 waves of 32x96) - the shape the automatic policy takes at the
+  reference's document-mask micro-batch (config_doc_mask.yaml:35: B = 8 -> M = 8192: N = 768 is ONE round of 256 tiles, N = 2304 three).
+  Bit-equal to the 256x256 tile on exactly representable inputs (any summation order), the automatic policy's result equals the explicit
+  variant's bits on random inputs, ragged M / N, and the RoPE epilogue on this tile gives the bits of GEMM + stand-alone pass."""
+  g = torch.Generator(device='cuda').manual_seed(75)
+  for M, N, K in ((8192, 768, 768), (8192, 2304, 768), (8192, 768, 4096), (4100, 1160, 192), (16384, 1024, 1024)):
     Ai = bf(torch.randint(-3, 4, (M, K), generator=g, device='cuda').float())
     Bi = bf(torch.randint(-3, 4, (N, K), generator=g, device='cuda').float())
-    assert torch.equal(ops.gemm_nt(Ai, Bi, variant=7), ops.gemm_nt(Ai, Bi, variant=4)), (M, N, K)  # small integers: exact in any order
+    assert torch.equal(ops.gemm_nt(Ai, Bi, variant=7), ops.gemm_nt(Ai, Bi, variant=4)), (M, N, K)
+    assert torch.equal(ops.gemm_nt(Ai, Bi), ops.gemm_nt(Ai, Bi, variant=4)), (M, N, K)
+    A = bf(torch.randn(M, K, generator=g, device='cuda'))
+    B = bf(torch.randn(N, K, generator=g, device='cuda'))
+    close(ops.gemm_nt(A, B, variant=7).float(), A.float() @ B.float().t(), 6e-3, f'128x192 tile {M}x{N}x{K}')
+    del Ai, Bi, A, B
+  # M = 8192: the automatic policy is on the 128x192 tile for N = 768 / 2304 (same bits as the explicit variant: same kernel)
+  A = bf(torch.randn(8192, 768, generator=g, device='cuda'))
+  for N in (768, 2304):
+    B = bf(torch.randn(N, 768, generator=g, device='cuda'))
+    assert torch.equal(ops.gemm_nt(A, B), ops.gemm_nt(A, B, variant=7)), N
+  for B_, T, nh, K in ((8, 1024, 12, 768), (8, 1000, 12, 768), (16, 512, 12, 768)):
+    d = nh * 64
+    x = bf(torch.randn(B_ * T, K, generator=g, device='cuda'))
+    w = bf(0.1 * torch.randn(3 * d, K, generator=g, device='cuda'))
+    cos, sin = (t.cuda() for t in O.rope_table(64, T))
+    got = ops.qkv_rope(x, w, cos, sin, B_, T, nh)
+    two = ops.gemm_nt(x, w)
+    if B_ * T == 8192:
+      assert torch.equal(two, ops.gemm_nt(x, w, variant=7))
+    ops.rope_qk_(two, cos, sin, B_, T, nh)
+    assert torch.equal(got, two), (B_, T, nh, K)
 
 
 def test_fused_entry_points_fall_back_under_gemm_v1(ops, plm_env):

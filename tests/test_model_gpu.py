@@ -550,10 +550,10 @@ def test_rccl_reducer_single_rank(P, mdl):
   m.sink.on_ready = red.param_ready
   fired = []
   orig = comm.allreduce_avg_
-  comm.allreduce_avg_ = lambda span, stream: (fired.append(span.numel()), orig(span, stream))[1]
+  comm.allreduce_avg_ = lambda span, stream, algo=None: (fired.append(span.numel()), orig(span, stream, algo))[1]
   # CUs are set aside for GEMMs that are expected to run beside a collective: a window of estimated GPU time behind every bucket
   # launch.  Pinned here to "a collective takes a second" (every GEMM enqueued after the first bucket launch is inside a window) ...
-  red.model_gbps, red.bucket_secs = 1e-9, [1.0] * len(red.buckets)
+  red.frozen, red.bucket_secs = True, [1.0] * len(red.buckets)
   seen = []
   real_set = ops.set_cu_reserve
   ops.set_cu_reserve = lambda n: (seen.append(n), real_set(n))[1]
@@ -579,35 +579,62 @@ def test_rccl_reducer_single_rank(P, mdl):
     red.finish()
     torch.cuda.synchronize()
     assert seen == [] and ops.cu_reserve() == 0 and torch.equal(m._flat_grad, want)
-    # the reduce-scatter + all-gather spelling of the mean (PLM_COMM_ALGO=rsag): one rank, so again the identity - spans that do and do not
-    # divide by the world size take the same calls
-    os.environ['PLM_COMM_ALGO'] = 'rsag'
-    try:
+    # the reduce-scatter + all-gather spelling of the mean (algo 'rsag'; PLM_COMM_ALGO is the default when the reducer has none): one rank,
+    # so again the identity - spans that do and do not divide by the world size take the same calls
+    for via_env in (True, False):
+      if via_env:
+        os.environ['PLM_COMM_ALGO'] = 'rsag'
+      else:
+        red.algo = 'rsag'
+      try:
+        m.sink.begin_window()
+        red.begin(sync=True)
+        m.loss(ids, tgt).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(m._flat_grad, want)
+      finally:
+        os.environ.pop('PLM_COMM_ALGO', None)
+        red.algo = None
+    # measured durations ('frozen' mode, the default): begin() folds the previous step's collectives into the table and the clock scale
+    # for FREEZE_AFTER communicating steps, then the table is agreed (one rank: kept) and never changes again
+    red.configure(reserve_cus=16)  # drops what was pinned above
+    assert red.window_mode == 'frozen' and not red.frozen and red.rate_scale == 1.0
+    tables = []
+    for i in range(ddp.FREEZE_AFTER + 3):
       m.sink.begin_window()
       red.begin(sync=True)
       m.loss(ids, tgt).backward()
       red.finish()
       torch.cuda.synchronize()
-      assert torch.equal(m._flat_grad, want)
-    finally:
-      del os.environ['PLM_COMM_ALGO']
-    # measured durations: with the model switched off, begin() folds the previous step's collectives into the estimate
-    red.model_gbps = None
+      tables.append((list(red.bucket_secs), red.rate_scale, red.frozen))
+    assert not tables[0][2] and tables[-1][2]
+    assert tables[-1][:2] == tables[-2][:2] == tables[-3][:2]  # frozen: the same windows (hence the same GEMM plans) every step
+    assert tables[0][0] != tables[-1][0] and all(0.0 < v < 0.05 for v in tables[-1][0])  # learned: 1-rank copies, clamped to bytes / 400 GB/s at least
+    assert 0.25 <= red.rate_scale <= 4.0 and red.rate_scale != 1.0
+    st = red.stats()
+    assert st['frozen'] and st['exposed_comm_ms'] is not None and st['exposed_comm_ms'] >= 0.0 and 0.0 <= st['reserved_launch_frac'] <= 1.0
+    # a step that raises between begin() and finish() must not leave the hook / the reserve behind
+    red.frozen, red.bucket_secs = True, [1.0] * len(red.buckets)
+    m.sink.begin_window()
     red.begin(sync=True)
-    assert all(0.0 < s < 0.05 for s in red.bucket_secs)  # half of zero + half of a few microseconds of 1-rank copies
-    red.finish()
+    m.loss(ids, tgt).backward()
+    assert ops.cu_reserve() == 16 and ops.LAUNCH_HOOK is not None
+    red.abort()
+    assert ops.cu_reserve() == 0 and ops.LAUNCH_HOOK is None and not red.sync
+    torch.cuda.synchronize()
   finally:
     ops.set_cu_reserve = real_set
   comm.close()
 
 
 @pytest.mark.timeout(300, method='thread')  # a hung ncclCommSplit must end the run, not the box
-def test_rccl_capped_communicator_and_split_tail_single_rank(P, mdl, monkeypatch):
-  """The communicator pair multi-GPU runs use under PLM_COMM_TAIL=1 (plainlm_amd/ddp.py::make_comm / make_tail_comm), on one GPU:
-  plm_comm_init_capped with maxCTAs = 16 (ncclCommInitRankConfig), plm_comm_split for the uncapped tail communicator
-  (ncclCommSplit), GradReducer routing the last bucket (embed_tokens + norm weights) through the child.  One rank: the mean
-  is the identity, so the flat gradient must be bit-equal to the un-reduced one, and the tail bucket must have gone
-  through the split communicator, every other bucket through the capped parent."""
+def test_rccl_comm_set_capped_children_and_uncapped_tail_single_rank(P, mdl, monkeypatch):
+  """The communicator set multi-GPU runs use (plainlm_amd/ddp.py::make_comm_set / pick_comms), on one GPU: an uncapped root
+  (ncclCommInitRank) + one ncclCommSplit child per cap with ncclConfig_t.maxCTAs (plm_comm_split) - what bench.py's autotune switches
+  between - and GradReducer routing the last bucket (embed_tokens + norm weights) through the uncapped root.  One rank: the mean is the
+  identity, so the flat gradient must be bit-equal to the un-reduced one, the tail bucket must have gone through the root and every
+  other bucket through the capped child; then the same after configure() has switched cap, algorithm and tail policy."""
   from plainlm_amd import ddp, ops
   m = _small(P, mdl, main_grad=True)
   tok = mdl['tokens']
@@ -616,44 +643,58 @@ def test_rccl_capped_communicator_and_split_tail_single_rank(P, mdl, monkeypatch
   m.loss(ids, tgt).backward()
   torch.cuda.synchronize()
   want = m._flat_grad.clone()
-  comm = ddp.RcclComm(0, 1, torch.cuda.current_device(), max_ctas=16)
-  assert comm.max_ctas == 16
-  assert ddp.make_tail_comm(comm) is None  # opt-in until a multi-GPU run has been recorded
-  monkeypatch.setenv('PLM_COMM_TAIL', '1')
-  tail = ddp.make_tail_comm(comm)
-  assert isinstance(tail, ddp.RcclComm) and tail.max_ctas == 0 and tail.handle.value != comm.handle.value
-  red = ddp.GradReducer(m._flat_grad, list(m.parameters()), m._grad_spans, comm, bucket_cap_mb=0.25, force=True, reserve_cus=16,
+  monkeypatch.delenv('NCCL_MAX_NCHANNELS', raising=False)
+  comms = ddp.make_comm_set('cuda', caps=(8, 16))
+  assert sorted(comms) == [0, 8, 16] and all(isinstance(c, ddp.RcclComm) for c in comms.values())
+  assert [comms[k].max_ctas for k in (0, 8, 16)] == [0, 8, 16] and len({c.handle.value for c in comms.values()}) == 3
+  assert 'NCCL_MAX_NCHANNELS' not in os.environ  # the caps are per communicator; the process-wide variable is the user's
+  comm, tail, reserve = ddp.pick_comms(comms)  # defaults: PLM_COMM_CUS = 16, tail through the uncapped root
+  assert comm is comms[16] and tail is comms[0] and reserve == 16
+  assert ddp.pick_comms(comms, cap=0) == (comms[0], None, 0) and ddp.pick_comms(comms, cap=8, tail=False) == (comms[8], None, 8)
+  assert ddp.pick_comms(comms, cap=12)[0] is comms[0] and ddp.pick_comms(comms, cap=12)[2] == 12  # no such child: root + GEMM-side reserve
+  monkeypatch.setenv('PLM_COMM_TAIL', '0')
+  assert ddp.pick_comms(comms)[1] is None
+  monkeypatch.delenv('PLM_COMM_TAIL')
+  red = ddp.GradReducer(m._flat_grad, list(m.parameters()), m._grad_spans, comm, bucket_cap_mb=0.25, force=True, reserve_cus=reserve,
                         comm_tail=tail)
   assert len(red.buckets) >= 4
   m.sink.on_ready = red.param_ready
-  seen = {'parent': [], 'tail': []}
-  for name, c in (('parent', comm), ('tail', tail)):
+  seen = {k: [] for k in comms}
+  for k, c in comms.items():
     orig = c.allreduce_avg_
-    c.allreduce_avg_ = (lambda span, stream, _o=orig, _n=name: (seen[_n].append((span.data_ptr(), span.numel())), _o(span, stream))[1])
-  for _ in range(2):  # twice: the second window re-uses both communicators
-    seen['parent'].clear(); seen['tail'].clear()
+    c.allreduce_avg_ = (lambda span, stream, algo=None, _o=orig, _k=k: (seen[_k].append((span.data_ptr(), span.numel(), algo)), _o(span, stream, algo))[1])
+  lo, hi, _ = red.buckets[red.tail_bucket]
+  for cap, algo, use_tail in ((16, None, True), (16, None, True), (8, 'rsag', True), (8, 'allreduce', False), (0, 'rsag', False)):
+    if (cap, algo, use_tail) != (16, None, True):
+      c, t, r = ddp.pick_comms(comms, cap=cap, tail=use_tail)
+      red.configure(comm=c, comm_tail=t, reserve_cus=r, algo=algo)
+    for v in seen.values():
+      v.clear()
     m.sink.begin_window()
     red.begin(sync=True)
     m.loss(ids, tgt).backward()
     red.finish()
     torch.cuda.synchronize()
-    lo, hi, _ = red.buckets[red.tail_bucket]
-    assert seen['tail'] == [(m._flat_grad[lo:hi].data_ptr(), hi - lo)]       # exactly the tail bucket, once
-    assert len(seen['parent']) == len(red.buckets) - 1
-    assert sum(n for _, n in seen['parent']) + (hi - lo) == m._flat_grad.numel()
+    tail_key = 0 if use_tail else cap
+    assert (m._flat_grad[lo:hi].data_ptr(), hi - lo, algo) in seen[tail_key]
+    if use_tail and cap:
+      assert seen[0] == [(m._flat_grad[lo:hi].data_ptr(), hi - lo, algo)]       # exactly the tail bucket, once
+      assert len(seen[cap]) == len(red.buckets) - 1
+    assert sum(n for v in seen.values() for _, n, _ in v) == m._flat_grad.numel()
+    assert all(not v for k, v in seen.items() if k not in (cap, tail_key))
     assert torch.equal(m._flat_grad, want)
   assert ops.cu_reserve() == 0
-  # broadcast through both (rank-0 parameters at wrap time use the parent; the child must be a working communicator too)
+  # broadcast through all of them (rank-0 parameters at wrap time use the capped one; every child must be a working communicator)
   buf = torch.arange(1024, dtype=torch.float32, device='cuda')
   st = torch.cuda.Stream()
   st.wait_stream(torch.cuda.current_stream())
-  for c in (comm, tail):
+  for c in comms.values():
     c.broadcast_(buf, 0, st)
     c.allreduce_avg_(buf, st)
   st.synchronize()
   assert torch.equal(buf, torch.arange(1024, dtype=torch.float32, device='cuda'))
-  tail.close()
-  comm.close()
+  for k in (16, 8, 0):
+    comms[k].close()
 
 
 def test_flat_adamw_matches_torch_adamw_and_clip(P, mdl):

@@ -1,6 +1,7 @@
-"""Per-kernel micro-benchmarks at the 160M shapes (B=32, T=1024, d=768, h=2048, V=50280).
+"""Per-kernel micro-benchmarks at the shapes of a BASELINE config: 160M (default: B=32, T=1024, d=768, h=2048, V=50280; --B 8 = the
+reference's document-mask micro-batch, config_doc_mask.yaml:35) or --config 420m (B=8, T=2048, d=1024, nh=16, h=2816; tr_420M_x8gpu.yaml).
 Prints achieved TFLOP/s (MFMA kernels) or GB/s of ALGORITHMIC bytes (HBM kernels).
-Usage: python tools/kbench.py [--iters 20] [--only gemm,attn,...]
+Usage: python tools/kbench.py [--iters 20] [--only gemm,attn,...] [--config 420m] [--B 8] [--doc-mask] [--variants]
 """
 
 import argparse
@@ -51,8 +52,10 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--iters', type=int, default=20)
   ap.add_argument('--only', default='')
-  ap.add_argument('--B', type=int, default=32)
-  ap.add_argument('--T', type=int, default=1024)
+  ap.add_argument('--config', default='160m', choices=['160m', '420m'])
+  ap.add_argument('--B', type=int, default=0)
+  ap.add_argument('--T', type=int, default=0)
+  ap.add_argument('--doc-mask', action='store_true', help='attention with document masks (mean document length 256) beside the causal kernels')
   ap.add_argument('--json', default='')
   ap.add_argument('--cu-reserve', type=int, default=0, help='CUs the persistent GEMMs leave free (what a data-parallel run sets during backward)')
   ap.add_argument('--variants', action='store_true', help='also time every NT kernel variant per shape')
@@ -61,8 +64,10 @@ def main():
   only = set(a.only.split(',')) if a.only else None
   if a.cu_reserve:
     ops.set_cu_reserve(a.cu_reserve)
-  B, T, d, nh, h, V = a.B, a.T, 768, 12, 2048, 50280
+  B, T, d, nh, h, V = {'160m': (32, 1024, 768, 12, 2048, 50280), '420m': (8, 2048, 1024, 16, 2816, 50280)}[a.config]
+  B, T = a.B or B, a.T or T
   M = B * T
+  n_params = 12 * (4 * d * d + 3 * d * h) * (1 if a.config == '160m' else 2) + 2 * V * d
   dev = 'cuda'
   rows = []
 
@@ -94,7 +99,7 @@ def main():
         del os.environ['PLM_NT_NO_HYBRID']
         ops.reload_env()
       if k % 64 == 0 and a.variants:
-        for v, vn in ((2, 'dma128'), (3, 'plain256x256'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128')):
+        for v, vn in ((2, 'dma128'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128'), (7, 'deep128x192')):
           rec(f'{name} [{vn}]', timeit(lambda: ops.gemm_nt(A, Bm, out=out, variant=v), a.iters), flops=2.0 * m * n * k)
         rec(f'{name} [auto again]', timeit(lambda: ops.gemm_nt(A, Bm, out=out), a.iters), flops=2.0 * m * n * k)
       if k % 64 == 0 and a.instep and n < 10000:
@@ -102,7 +107,7 @@ def main():
                 for _ in range(4)]
         big = torch.randn(M, 4096, device=dev).to(BF)
         between = lambda: ops.swiglu_fwd(big)  # 268 MB read + 134 MB written: evicts L2 / most of the Infinity Cache
-        for v, vn in ((0, 'auto'), (3, 'plain256x256'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128')):
+        for v, vn in ((0, 'auto'), (4, 'deep256x256'), (5, 'deep256x192'), (6, 'deep256x128'), (7, 'deep128x192')):
           fns = [(lambda X=X, W=W, O=O: ops.gemm_nt(X, W, out=O, variant=v)) for X, W, O in sets]
           rec(f'{name} [in-step {vn}]', timeit_instep(fns, a.iters, between), flops=2.0 * m * n * k)
         del sets, big
@@ -132,47 +137,6 @@ def main():
         del os.environ['PLM_TN_NO_BIG']
         ops.reload_env()
       del A, Bm, out
-
-  if want('duo'):
-    # the two-workgroups-per-CU 256x128 family (gemm_duo.hip) against the one-workgroup-per-CU kernels, same process, interleaved
-    from oracle import cpu_ref as O_
-    cos, sin = (t.cuda() for t in O_.rope_table(64, T))
-    A = torch.randn(M, d, device=dev).to(BF)
-    W1 = (torch.randn(2 * h, d, device=dev) * 0.02).to(BF)
-    W2T = (torch.randn(h, d, device=dev) * 0.02).to(BF)
-    Um = torch.randn(M, 2 * h, device=dev).to(BF)
-    Wq = (torch.randn(3 * d, d, device=dev) * 0.02).to(BF)
-    Wo = (torch.randn(d, d, device=dev) * 0.02).to(BF)
-    outo = torch.empty(M, d, device=dev, dtype=BF)
-    cases = {'fc1 + swiglu': (lambda: ops.fc1_swiglu(A, W1), 2.0 * M * 2 * h * d),
-             'dX fc2 + swiglu bwd': (lambda: ops.fc2_dx_swiglu_bwd(A, W2T, Um), 2.0 * M * h * d),
-             'qkv + rope': (lambda: ops.qkv_rope(A, Wq, cos, sin, B, T, nh), 2.0 * M * 3 * d * d)}
-    def setenv(**kv):
-      for k, v in kv.items():
-        if v is None:
-          os.environ.pop(k, None)
-        else:
-          os.environ[k] = v
-      ops.reload_env()
-    for rnd in range(2):
-      for name, (fn, fl) in cases.items():
-        setenv(PLM_NT_DUO='0', PLM_DUO_STAGGER_US=None)
-        rec(f'{name} [1 wg/cu] r{rnd}', timeit(fn, a.iters), flops=fl)
-        for stg in (None, '0', '2', '4', '6', '9'):
-          setenv(PLM_NT_DUO='7', PLM_DUO_STAGGER_US=stg)
-          rec(f'{name} [duo stagger {stg}] r{rnd}', timeit(fn, a.iters), flops=fl)
-      setenv(PLM_NT_DUO=None, PLM_DUO_STAGGER_US=None)
-      for name, (m, n, k) in {'nt out fwd': (M, d, d), 'nt qkv fwd': (M, 3 * d, d), 'nt fc1 fwd': (M, 2 * h, d), 'nt dX fc2': (M, h, d), 'nt fc2 fwd': (M, d, h)}.items():
-        X = torch.randn(m, k, device=dev).to(BF)
-        W = (torch.randn(n, k, device=dev) * 0.02).to(BF)
-        o = torch.empty(m, n, device=dev, dtype=BF)
-        rec(f'{name} [auto] r{rnd}', timeit(lambda: ops.gemm_nt(X, W, out=o), a.iters), flops=2.0 * m * n * k)
-        for stg in (None, '0', '4'):
-          setenv(PLM_DUO_STAGGER_US=stg)
-          rec(f'{name} [duo stagger {stg}] r{rnd}', timeit(lambda: ops.gemm_nt(X, W, out=o, variant=7), a.iters), flops=2.0 * m * n * k)
-        setenv(PLM_DUO_STAGGER_US=None)
-        del X, W, o
-    del A, W1, W2T, Um, Wq, Wo, outo
 
   if want('gemm'):
     shp = [(d, h), (2 * h, d), (d, d), (3 * d, d)]  # fc2, fc1, w_out, w_qkv: the dW GEMMs of one block
@@ -205,6 +169,24 @@ def main():
     rec('rope qk (in place)', timeit(lambda: ops.rope_qk_(qkv, cos, sin, B, T, nh), a.iters), bytes_=8.0 * M * d)
     rec('attn fwd', timeit(lambda: ops.attn_fwd(qkv, B, T, nh), a.iters), flops=fl)
     rec('attn bwd', timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh), a.iters), flops=2.0 * fl)
+    if a.doc_mask:
+      import numpy as np
+      from plainlm_amd.engine import doc_start_from_lengths
+      rng = np.random.default_rng(7)
+      docs = []
+      for _ in range(B):
+        lens, tot = [], 0
+        while tot < T + 1:
+          n = int(min(rng.geometric(1.0 / 256.0), T + 1 - tot))
+          lens.append(n)
+          tot += n
+        docs.append(lens)
+      ds = doc_start_from_lengths(docs, T).to(dev)
+      pos = torch.arange(T, device=dev)[None, :]
+      fl_m = float((4.0 * nh * 64 * (pos - ds + 1)).sum())  # visible (query, key) pairs x 2 matmuls x 2 flop x head_dim
+      out_m, lse_m = ops.attn_fwd(qkv, B, T, nh, ds)
+      rec('attn fwd (doc masks, mean length 256; flops of the visible pairs)', timeit(lambda: ops.attn_fwd(qkv, B, T, nh, ds), a.iters), flops=fl_m)
+      rec('attn bwd (doc masks)', timeit(lambda: ops.attn_bwd(qkv, out_m, dout, lse_m, cos, sin, B, T, nh, ds), a.iters), flops=2.0 * fl_m)
 
   if want('hbm'):
     x = torch.randn(M, d, device=dev)
@@ -231,10 +213,10 @@ def main():
     rec('embed bwd (sorted, writes all of dW)', timeit(lambda: ops.embed_bwd_sorted(ids, x, dW, False), a.iters), bytes_=4.0 * M * d + 4.0 * V * d)
     P = torch.randn(2304, 768, device=dev)
     rec('cast+transpose qkv', timeit(lambda: ops.cast_bf16_t(P), a.iters), bytes_=8.0 * P.numel())
-    flat = torch.randn(162_183_936, device=dev)
-    rec('sumsq 162M', timeit(lambda: ops.sumsq(flat), a.iters), bytes_=4.0 * flat.numel())
+    flat = torch.randn(n_params, device=dev)
+    rec(f'sumsq {n_params / 1e6:.0f}M', timeit(lambda: ops.sumsq(flat), a.iters), bytes_=4.0 * flat.numel())
     m_, v_, g_ = torch.zeros_like(flat), torch.zeros_like(flat), torch.randn_like(flat)
-    rec('adamw 162M', timeit(lambda: ops.adamw_(flat, g_, m_, v_, 1e-3, 0.9, 0.95, 1e-8, 0.1, 1), a.iters), bytes_=28.0 * flat.numel())
+    rec(f'adamw {n_params / 1e6:.0f}M', timeit(lambda: ops.adamw_(flat, g_, m_, v_, 1e-3, 0.9, 0.95, 1e-8, 0.1, 1), a.iters), bytes_=28.0 * flat.numel())
 
   if a.json:
     with open(a.json, 'w') as f:
