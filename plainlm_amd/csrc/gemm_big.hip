@@ -450,7 +450,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
     // ---- epilogue: 32-row x 64-col pieces through this wave's private 4 KiB scratch ----
     // alpha is 1 for every launch of the step but lm_head's dX: the 4 * AF * 2 * NBF * 4 multiplies are taken only when a device scalar
     // was passed (x * 1.0f is exact, so the bits do not depend on which way the branch goes)
-    if (alpha_dev != nullptr) {
+    // (HYB: always - with the branch hipcc keeps two copies of the accumulators alive across the slab / tile paths of that instantiation:
+    // 256 VGPRs + 59 spills since round 4's conditional, 236 and none without it; found in round 5 by tools/isa_scan.py)
+    if (HYB || alpha_dev != nullptr) {
 #pragma unroll
       for (int i = 0; i < 2 * NA; ++i)
 #pragma unroll
@@ -1164,12 +1166,13 @@ __global__ __launch_bounds__(256) void nt_streamk_reduce_kernel(const float* __r
 // 256x256 at 0.90 round efficiency beats 256x128 at 1.0 on the qkv shape.  128x192 (round 5; 8 waves of 32x96) is the shape of the
 // short batches: M = 8192 (the reference's document-mask config, config_doc_mask.yaml:35) makes N = 768 exactly ONE round of 256 tiles
 // and N = 2304 exactly three, where every 256-row tile leaves 25-62 % of the chip idle.
+// Rates fitted on gpurun_out/r05b kbench --variants tables at M = 8192 / 16384 / 32768 (profiles/r05_kbench_variants.txt).
 // Order = preference on ties (the first strictly greater wins).
 struct NtTileShape {
   int bm, bn;
   double rate;
 };
-static const NtTileShape kNtTiles[4] = {{256, 256, 1.0}, {256, 128, 0.88}, {256, 192, 0.94}, {128, 192, 0.80}};
+static const NtTileShape kNtTiles[4] = {{256, 256, 1.0}, {256, 128, 0.88}, {256, 192, 0.94}, {128, 192, 0.72}};
 static const int kNtTileVariant[4] = {4, 6, 5, 7};  // the explicit variant number of each (plm_gemm_bf16_nt_ex)
 static double nt_tile_eff(int i, int64_t M, int64_t N, int slots) {
   const NtTileShape& t = kNtTiles[i];

@@ -247,12 +247,20 @@ class GradReducer:
     """Forget what was learned about the collectives' durations and the clock (a different communicator / algorithm / cap)."""
     gbps = self.model_gbps or 60.0
     self.bucket_secs = [nb / (gbps * 1e9) for nb in self._bucket_bytes]
-    self._timing = {}          # bucket -> (start event, end event) of its last collective
-    self._span = None          # (event at begin(), event at finish(), estimated clock at finish()) of the last communicating step
-    self.rate_scale = 1.0      # measured / estimated GPU time from begin() to finish(): rescales _FAMILY_RATE
-    self.sync_steps = 0
+    # Measurements of the communicating steps still in flight, oldest first: {'buckets': {b: (start, end)}, 'span': (event at begin(),
+    # event in front of the join, estimated clock there)}.  The host runs a step or two ahead of the GPU, so a step's events are read
+    # when a LATER begin() finds them complete - never waited for, except once, at the freeze.
+    self._hist = []
+    self._cur = None
+    self._event_pool = []
+    self.rate_scale = 1.0      # measured / estimated GPU time from begin() to the join: rescales _FAMILY_RATE
+    self.sync_steps = 0        # communicating steps begun since the last reset
+    self.learned_steps = 0     # ... whose measurements have been folded in
     self.frozen = self.window_mode == 'model'
     self.clock, self.window_end = 0.0, -1.0
+
+  def _event(self):
+    return self._event_pool.pop() if self._event_pool else torch.cuda.Event(enable_timing=True)
 
   def configure(self, comm=None, comm_tail=False, reserve_cus=None, algo=None):
     """Switch the data plane between two steps (bench.py's autotune): any of the communicator used while backward runs, the one
@@ -269,27 +277,44 @@ class GradReducer:
       self.algo = algo
     self.reset_windows()
 
+  def _fold(self, rec):
+    for b, (t0, t1) in rec['buckets'].items():
+      # clamped to bytes / 400 GB/s ... bytes / 10 GB/s: a collective measured while a rank was late (or a 1-rank local copy) must
+      # not switch the reserve off for good or hold it for the whole of backward
+      secs = min(max(t0.elapsed_time(t1) * 1e-3, self._bucket_bytes[b] / 400e9), self._bucket_bytes[b] / 10e9)
+      self.bucket_secs[b] = secs if self.learned_steps == 0 else 0.5 * self.bucket_secs[b] + 0.5 * secs
+      self._event_pool += [t0, t1]
+    if rec['span'] is not None:
+      t0, t1, est, scale = rec['span']
+      if est > 0:
+        new = scale * (t0.elapsed_time(t1) * 1e-3) / est  # est was computed with `scale`
+        self.rate_scale = min(max(new if self.learned_steps == 0 else 0.5 * self.rate_scale + 0.5 * new, 0.25), 4.0)
+      self._event_pool += [t0, t1]
+    self.learned_steps += 1
+
   def _learn(self):
-    """Top of a communicating step: fold the previous step's measurements (finished: finish() joined the streams and the caller has
-    run a whole forward since... or not - unfinished events are skipped) into the window table and the clock scale; in 'frozen'
-    mode agree on them across the ranks after FREEZE_AFTER steps and stop."""
+    """Top of a communicating step: fold the measurements of earlier steps that have finished on the GPU into the window table and
+    the clock scale.  'frozen' mode: at the top of step FREEZE_AFTER + 1 (the same step on every rank - the agreement is a collective)
+    the host waits ONCE for the steps it has enqueued, folds them, the ranks agree on the elementwise maximum, and nothing changes
+    any more; 'ema' keeps following; 'model' never measures."""
     if self.frozen:
       return
-    for b, (s, e) in list(self._timing.items()):
-      if e.query():
-        # clamped to bytes / 400 GB/s ... bytes / 10 GB/s: a collective measured while a rank was late (or a 1-rank local copy) must
-        # not switch the reserve off for good or hold it for the whole of backward
-        secs = min(max(s.elapsed_time(e) * 1e-3, self._bucket_bytes[b] / 400e9), self._bucket_bytes[b] / 10e9)
-        self.bucket_secs[b] = 0.5 * self.bucket_secs[b] + 0.5 * secs
-    if self._span is not None:
-      t0, t1, est = self._span
-      if t1.query() and est > 0:
-        scale = self.rate_scale * (t0.elapsed_time(t1) * 1e-3) / est  # est was computed WITH the current scale
-        self.rate_scale = min(max(0.5 * self.rate_scale + 0.5 * scale, 0.25), 4.0)
-    if self.window_mode == 'frozen' and self.sync_steps >= FREEZE_AFTER:
+    freeze_now = self.window_mode == 'frozen' and self.sync_steps >= FREEZE_AFTER
+    while self._hist and self._hist[0] is not self._cur:
+      rec = self._hist[0]
+      ends = [t1 for _, t1 in rec['buckets'].values()] + ([rec['span'][1]] if rec['span'] is not None else [])
+      if not all(e.query() for e in ends):
+        if not freeze_now:
+          break
+        for e in ends:
+          e.synchronize()
+      self._hist.pop(0)
+      self._fold(rec)
+    if freeze_now:
       vals = agree_max_floats(self.bucket_secs + [self.rate_scale], self.ctl_group)
       self.bucket_secs, self.rate_scale = vals[:-1], vals[-1]
       self.frozen = True
+      self._hist = []
 
   def begin(self, sync):
     if self.on_gpu and (self._reserved or self.sync):
@@ -303,13 +328,17 @@ class GradReducer:
     if self.on_gpu and self.sync:
       self._learn()
       self.sync_steps += 1
+      self._cur = None
+      if not self.frozen:
+        self._cur = {'buckets': {}, 'span': None, 't0': None}
+        if len(self._hist) < 8:  # a GPU that never catches up (it does): stop recording rather than grow
+          self._hist.append(self._cur)
       if self.reserve_cus:
         from . import ops
         ops.LAUNCH_HOOK = self._on_launch
-        if not self.frozen:
-          t0 = torch.cuda.Event(enable_timing=True)
-          t0.record()
-          self._span_begin = t0
+        if self._cur is not None:
+          self._cur['t0'] = self._event()
+          self._cur['t0'].record()
 
   def abort(self):
     """Drop the launch hook and the CU reserve (a step raised between begin() and finish(): 'Train loss is nan', out of memory);
@@ -322,6 +351,9 @@ class GradReducer:
         ops.set_cu_reserve(0)
         self._reserved = False
       torch.cuda.current_stream().wait_stream(self.stream)
+    if self._cur is not None:  # a half-recorded step is not a measurement
+      self._hist = [r for r in self._hist if r is not self._cur]
+      self._cur = None
     self.sync = False
 
   def _on_launch(self, family, flops):
@@ -369,11 +401,13 @@ class GradReducer:
       ev.record(torch.cuda.current_stream())
       self.stream.wait_event(ev)
       with torch.cuda.stream(self.stream):
-        t0, t1 = self._timing.get(b) or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        t0.record(self.stream)
+        if self._cur is not None:
+          t0, t1 = self._event(), self._event()
+          t0.record(self.stream)
         comm.allreduce_avg_(span, self.stream, self.algo)
-        t1.record(self.stream)
-        self._timing[b] = (t0, t1)
+        if self._cur is not None:
+          t1.record(self.stream)
+          self._cur['buckets'][b] = (t0, t1)
       # GEMMs enqueued inside this window may run beside the collective (see __init__)
       self.window_end = max(self.window_end, self.clock) + self.bucket_secs[b]
     else:
@@ -409,19 +443,22 @@ class GradReducer:
     if self.on_gpu:
       from . import ops
       cur = torch.cuda.current_stream()
+      if ops.LAUNCH_HOOK == self._on_launch:
+        ops.LAUNCH_HOOK = None
+        if self._cur is not None and self._cur.get('t0') is not None:
+          t1 = self._event()
+          t1.record(cur)  # measured vs estimated GPU time of this step's kernels, begin() ... in front of the join
+          self._cur['span'] = (self._cur['t0'], t1, self.clock, self.rate_scale)
       # the join, bracketed by events: what the compute stream waits here is the EXPOSED part of the step's communication
       e0, e1 = self._exposed or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
       e0.record(cur)
       cur.wait_stream(self.stream)
       e1.record(cur)
       self._exposed = (e0, e1)
-      if ops.LAUNCH_HOOK == self._on_launch:
-        ops.LAUNCH_HOOK = None
-        if not self.frozen and getattr(self, '_span_begin', None) is not None:
-          self._span = (self._span_begin, e0, self.clock)  # measured vs estimated GPU time of this step's kernels
       if self._reserved:  # everything enqueued after the join runs with no collective in flight
         ops.set_cu_reserve(0)
         self._reserved = False
+    self._cur = None
     self.sync = False
 
   def broadcast_params(self, flat_params_or_list):

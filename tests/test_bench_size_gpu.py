@@ -238,5 +238,48 @@ def test_160m_batch32_loss_and_all_gradients_vs_oracle(ops):
   worst = {n: relerr(got[n], og[n]) for n in got}
   top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
   print('160M batch-32 gradients vs fp32 oracle (rel-to-max), worst five:', [(n, f'{e:.1e}') for n, e in top])
-  bad = {n: e for n, e in worst.items() if e > 6e-2}
+  # per class (one 6e-2 across the board would pass a kernel that is 1e-2 wrong on a weight gradient): the RMSNorm weight
+  # gradients are 32768-row column sums of bf16-rounded products and sit at 1.8e-2 against the FP32 oracle (the emulating oracle below
+  # explains them); every Linear / embedding gradient is an fp32 GEMM sum and stays below 1e-2
+  norm_worst = max(e for n, e in worst.items() if 'norm' in n)
+  lin_worst = max(e for n, e in worst.items() if 'norm' not in n)
+  print(f'160M batch-32: worst norm-weight gradient {norm_worst:.1e}, worst Linear / embedding gradient {lin_worst:.1e}')
+  bad = {n: e for n, e in worst.items() if e > (4e-2 if 'norm' in n else 1.2e-2)}
+  assert not bad, bad
+
+
+def test_160m_batch32_launch_vs_bf16_emulating_oracle(ops):
+  """The bench's launch sizes against the oracle that rounds where the kernels round (oracle/cpu_ref_bf16.py; 5e-3 rel-to-max instead of
+  the fp32 comparison's per-cent tolerances), at the price of ONE pair of sequences on the CPU: the batch is that pair repeated 16 times,
+  so the batch-mean gradient IS the pair's gradient while every kernel runs its 32 x 1024-token launch (grids, tile schedules, split-K /
+  grouped dW plans, 32768-row column sums of the step bench.py times).  All 75 gradients and the loss."""
+  import plainlm_amd as P
+  from oracle import cpu_ref_bf16 as E
+  ocfg = O.OracleConfig(vocab_size=V160, seq_len=1024, dim=768, n_layers=12, n_heads=12)
+  w = O.init_params(ocfg, seed=33)
+  rng = np.random.default_rng(77)
+  pair = torch.from_numpy(rng.integers(0, V160, size=(2, 1025)))
+  tok = pair.repeat(16, 1)
+  ids, tgt = tok[:, :1024].contiguous(), tok[:, 1:].contiguous()
+  m = P.Transformer(P.ModelConfig(vocab_size=V160, seq_len=1024, dim=768, expand=8 / 3, n_layers=12, n_heads=12, mlp='glu'))
+  m.load_state_dict(w)
+  m = m.cuda()
+  m.enable_main_grad()
+  m.sink.begin_window()
+  loss = m.loss(ids.cuda(), tgt.cuda())
+  loss.backward()
+  m.attach_grads()
+  got = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+  lg = loss.item()
+  del m
+  torch.cuda.empty_cache()
+  eloss, eg = E.loss_and_grads(w, ocfg, pair[:, :1024], pair[:, 1:])
+  rel = abs(lg - eloss.item()) / abs(eloss.item())
+  print(f'160M 16 x pair: loss gpu {lg:.6f} bf16-emulating oracle {eloss.item():.6f} rel {rel:.2e}')
+  assert rel <= LOSS_RTOL
+  worst = {n: relerr(got[n], eg[n]) for n in got}
+  assert len(worst) == 75
+  top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+  print('160M 16 x pair gradients vs bf16-emulating oracle (rel-to-max), worst five:', [(n, f'{e:.1e}') for n, e in top])
+  bad = {n: e for n, e in worst.items() if e > 5e-3}
   assert not bad, bad

@@ -71,9 +71,9 @@ def _worker(rank, world, port, out_dir, tied, bucket_mb):
   calls = {'n': 0}
   orig = eng.reducer.comm.allreduce_avg_
 
-  def counting(span, stream=None):
+  def counting(span, stream=None, algo=None):
     calls['n'] += 1
-    return orig(span, stream)
+    return orig(span, stream, algo)
 
   eng.reducer.comm.allreduce_avg_ = counting
   tok = _tokens()

@@ -307,3 +307,37 @@ def test_buckets_keep_blocks_whole_and_dw_groups_end_at_bucket_boundaries():
   assert launched == [0, 1, 2, 3, 4, 5, 6]
   red.begin(sync=False)
   assert red.param_queued(params[first]) is None  # micro-steps that do not communicate: the sink's own count decides
+
+
+@pytest.mark.timeout(600)
+def test_no_register_spills_in_the_persistent_gemm_kernels():
+  """Round 4's conditional alpha multiply pushed the stream-K (HYB) instantiation of gemm_nt_big_kernel from 234 VGPRs to 256 + 59
+  spills (+30 % on every hybrid launch of a data-parallel run) and nobody looked: the kernel was still correct.  Compile
+  csrc/gemm_big.hip with the library's flags (hipcc cross-compiles without a GPU) and require: no VGPR / SGPR spill and no scratch in
+  any persistent GEMM kernel, and no draining `s_waitcnt vmcnt(0)` inside the K loops of the plain NT kernels."""
+  import re
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'isa_scan.py'), 'gemm_big.hip'], capture_output=True, text=True, timeout=540)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = r.stdout.splitlines()
+  kernels = {}
+  for i, l in enumerate(lines):
+    if l.startswith('void gemm_') or l.startswith('gemm_'):
+      meta = eval(lines[i + 1].strip())  # the dict isa_scan prints
+      kernels[l.strip()] = (meta, lines[i + 2] if i + 2 < len(lines) else '')
+  big = {k: v for k, v in kernels.items() if 'gemm_nt_big_kernel' in k or 'gemm_tn_big_kernel' in k}
+  assert len(big) >= 12, sorted(kernels)
+  for k, (meta, span) in big.items():
+    assert meta['vspill'] == 0 and meta['scratch'] == 0 and meta['vgpr'] <= 256, (k, meta)
+    if 'gemm_tn_big_kernel<true>' in k:
+      # the grouped dW kernel keeps its 48-problem tables (3.2 KB of kernel arguments) in SGPRs that hipcc parks in VGPR lanes: known and
+      # outside the K loop's critical path as long as the lane moves inside the MFMA span stay a handful (11 today)
+      m = re.search(r'v_readlane/v_writelane: (\d+)', span)
+      assert m and int(m.group(1)) <= 16, (k, span)
+    else:
+      assert meta['sspill'] == 0, (k, meta)
+    if 'gemm_nt_big_kernel' in k and k.endswith('false, false, false, false>'):  # plain and HYB instantiations: the K loop never drains the DMA ring
+      m = re.search(r'unconditional vmcnt\(0\): (\d+)', span)
+      assert m and int(m.group(1)) <= 1, (k, span)
