@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "plm_device.h"
 
@@ -44,6 +45,13 @@ __device__ __forceinline__ void wait_vm() {
 template <int N0, int N1>
 __device__ __forceinline__ void wait_vm_sel(int flag) {
   asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%1)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(%2)\n2:" ::"s"(flag), "n"(N0), "n"(N1)
+               : "memory", "scc");
+}
+// three-way form: flag 0 -> N0, 1 -> N1, anything else -> N2
+template <int N0, int N1, int N2>
+__device__ __forceinline__ void wait_vm_sel3(int flag) {
+  asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%1)\n\ts_branch 3f\n1:\n\ts_cmp_lg_u32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(%2)\n\t"
+               "s_branch 3f\n2:\n\ts_waitcnt vmcnt(%3)\n3:" ::"s"(flag), "n"(N0), "n"(N1), "n"(N2)
                : "memory", "scc");
 }
 // all of this wave's LDS reads have returned, then the workgroup barrier (never drains VMEM)
@@ -131,6 +139,67 @@ struct EpiArgs {
   int T, rope_cols;
 };
 
+template <class F, int... U>
+__device__ __forceinline__ void nt_for_units(F& f, std::integer_sequence<int, U...>) {
+  (f(std::integral_constant<int, U>{}), ...);
+}
+// Epilogue units of a wave tile and where each one leaves (see OVL in the kernel): NA 32-row pieces x NPASS column passes.
+template <int NA, int NBF, int BF0>
+struct NtOvlPlan {
+  static constexpr int NPASS = (NBF + 1) / 2, NUNIT = NA * NPASS;
+  static constexpr int pass_blocks(int u) { const int p0 = (u % NPASS) * 2; return NBF - p0 < 2 ? NBF - p0 : 2; }
+  static constexpr int stores(int u) { return 2 * pass_blocks(u); }
+  // phase of the last K-tile after which unit u is final: (A0,B0) 1, (A0,B1) 2, (A1,B1) 3, (A1,B0) 4
+  static constexpr int ready(int u) {
+    const int mf = u / NPASS, p0 = (u % NPASS) * 2, nb = pass_blocks(u);
+    const int h[2] = {(2 * mf) / NA, (2 * mf + 1) / NA};       // A halves of its two 16-row blocks
+    const bool b[2] = {p0 < BF0, p0 + nb - 1 >= BF0};           // B halves its 32-column blocks belong to
+    int r = 0;
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (b[j]) {
+          const int ph = h[i] == 0 ? (j == 0 ? 1 : 2) : (j == 1 ? 3 : 4);
+          r = ph > r ? ph : r;
+        }
+    return r;
+  }
+  // slot of unit u: 2 / 3 / 4 = inside that phase of the last K-tile, 5 = behind the loop; units in order of readiness take the earliest
+  // free phase behind their ready phase (one unit per phase: they share the wave's 4 KiB scratch)
+  static constexpr int slot(int u) {
+    bool taken[6] = {false, false, false, false, false, false};
+    int slot_u = 5;
+    for (int r = 1; r <= 4; ++r)
+      for (int v = 0; v < NUNIT; ++v)
+        if (ready(v) == r) {
+          int sl = 5;
+          for (int c = r + 1; c <= 4; ++c)
+            if (!taken[c]) {
+              sl = c;
+              break;
+            }
+          if (sl < 5) taken[sl] = true;
+          if (v == u) slot_u = sl;
+        }
+    return slot_u;
+  }
+  static constexpr int stores_in_slot(int sl) {
+    int n = 0;
+    for (int u = 0; u < NUNIT; ++u)
+      if (slot(u) == sl) n += stores(u);
+    return n;
+  }
+  static constexpr int unit_in_slot(int sl) {  // -1: none
+    for (int u = 0; u < NUNIT; ++u)
+      if (slot(u) == sl) return u;
+    return -1;
+  }
+};
+static_assert(NtOvlPlan<2, 3, 2>::slot(0) == 2 && NtOvlPlan<2, 3, 2>::slot(1) == 3 && NtOvlPlan<2, 3, 2>::slot(3) == 4 && NtOvlPlan<2, 3, 2>::slot(2) == 5,
+              "256x192: (A0,B0) (A0,B1) (A1,B1) leave in phases 2 3 4, (A1,B0) behind the loop");
+static_assert(NtOvlPlan<4, 2, 1>::slot(0) == 3 && NtOvlPlan<4, 2, 1>::slot(1) == 4 && NtOvlPlan<4, 2, 1>::slot(2) == 5 && NtOvlPlan<4, 2, 1>::slot(3) == 5,
+              "256x256: the two pieces of A half 0 leave in phases 3 and 4");
+static_assert(NtOvlPlan<1, 3, 2>::slot(1) == 4 && NtOvlPlan<1, 3, 2>::slot(0) == 5, "128x192: the B1 pass leaves in phase 4");
+
 template <int BM, int BN, int WM, int WN, bool HYB = false, bool GLU = false, bool GLUB = false, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                              const uint16_t* __restrict__ B, int64_t ldb,
@@ -168,6 +237,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
   // of them (vmcnt retires in order, so a plain count would wait for every store).
   constexpr int NS = NA * 2 * NBF * (GLUB ? 2 : 1) + (GLU ? NA * 2 : 0);
   static_assert(D_P1 + NS < 64, "vmcnt is a 6-bit counter");
+  // Overlapped epilogue (round 5; PLM_NT_OVL, plain epilogue only).  An epilogue UNIT = (32-row piece mf, column pass p0) of the wave tile.  In the
+  // LAST K-tile of a tile a quadrant of the accumulators is final as soon as its phase has run - (A0,B0) after phase 1, (A0,B1) after 2,
+  // (A1,B1) after 3, (A1,B0) after 4 - so a unit whose quadrants are all final leaves DURING the following phase: its packed bf16 values
+  // go into the wave's transposition scratch before the phase's MFMAs are issued, and are read back and stored behind them, under the
+  // matrix pipe's work instead of after the K loop.  256x192: units final after phases 1 / 2 / 3 / 4 -> three of four overlap; 256x256 and
+  // 256x128: the two A halves -> half overlaps; 128x192: the B1 pass.  The stores issued inside the K-tile are counted into every later
+  // vmcnt wait exactly (OVS_*: cumulative stores in front of each wait, per wave group - group 1 waits BEFORE its phase's MFMAs and
+  // stores), and into the next tile's first K-tile through credit value 2 (the B0 half-tile of the next tile's SECOND K-tile is issued in
+  // phase 3, after the phase-2 unit's stores: the waits for it may leave NS - OVS_2 stores outstanding, not NS).
+#ifndef PLM_NT_OVL
+#define PLM_NT_OVL 1
+#endif
+  constexpr bool OVL = PLM_NT_OVL && !HYB && !GLU && !GLUB && !ROPE;
+  using OP = NtOvlPlan<NA, NBF, BF0>;  // unit u = mf * NPASS + pass
+  constexpr int NPASS = OP::NPASS, NUNIT = OP::NUNIT;
+  constexpr int OVS_2 = OVL ? OP::stores_in_slot(2) : 0, OVS_3 = OVL ? OP::stores_in_slot(3) : 0, OVS_4 = OVL ? OP::stores_in_slot(4) : 0;
+  static_assert(OVS_2 + OVS_3 + OVS_4 + (OVL ? OP::stores_in_slot(5) : NS) == NS, "every unit has a slot");
+  static_assert(D_P4 + NS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 8 * 4096];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -352,20 +439,77 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // ---- epilogue units (plain epilogue): 32-row piece mf x column pass p0 through this wave's private 4 KiB scratch ----
+    auto unit_write = [&](auto utag) {  // accumulators -> packed bf16 -> scratch (lane owns 4 consecutive columns of a row)
+      constexpr int u = decltype(utag)::value, mf = u / NPASS, p0 = (u % NPASS) * 2, nb = OP::pass_blocks(u);
+#pragma unroll
+      for (int bq = 0; bq < nb; ++bq) {
+        const int bh = p0 + bq;
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr)  // 16-row half of the 32-row piece
+#pragma unroll
+          for (int sc = 0; sc < 2; ++sc) {  // 16-column half of the 32-column block: this lane holds columns 4 q .. 4 q + 3 of it
+            bf16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc4[2 * mf + sr][bh * 2 + sc][e]);
+            const int row = sr * 16 + l15, c = bq * 4 + sc * 2 + (q >> 1);
+            *reinterpret_cast<bf16x4_t*>(epi + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = o;
+          }
+      }
+    };
+    auto unit_store = [&](auto utag, auto interior, int m0, int n0) {  // scratch -> whole row segments (16 bytes per lane, 8 or 4 lanes per row)
+      constexpr int u = decltype(utag)::value, mf = u / NPASS, p0 = (u % NPASS) * 2, nb = OP::pass_blocks(u);
+      const int mrow0 = m0 + wm * TM + mf * 32;
+      bf16x8_t v[2 * nb];
+#pragma unroll
+      for (int it = 0; it < 2 * nb; ++it) {
+        const int c = it * 64 + lane;
+        const int row = nb == 2 ? c >> 3 : c >> 2, ch = nb == 2 ? c & 7 : c & 3;
+        v[it] = *reinterpret_cast<const bf16x8_t*>(epi + row * 128 + ((ch ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int it = 0; it < 2 * nb; ++it) {
+        const int c = it * 64 + lane;
+        const int row = nb == 2 ? c >> 3 : c >> 2, ch = nb == 2 ? c & 7 : c & 3;
+        const int gm = mrow0 + row;
+        const int gn = n0 + wn * TN + p0 * 32 + ch * 8;
+        if (decltype(interior)::value || (gm < M && gn < N)) st_c_bf16x8(C + (int64_t)gm * ldc + gn, v[it]);  // interior tile: no predicate, no branch
+      }
+    };
+
+    // One K-tile.  LASTOVL = the last K-tile of an interior tile with the overlapped epilogue (see OVL): the unit of slot p is written
+    // into the scratch in front of phase p's MFMAs and stored behind them; its stores are counted into the waits behind them.
+    auto ktile = [&](auto lasttag, int m0, int n0) {
+      constexpr bool LASTOVL = decltype(lasttag)::value;
       // The staging cursor never runs dry: when a workgroup is out of K-tiles it re-stages its last one into slots nobody reads
       // again (a few KiB of L2 hits per workgroup), so the DMA issue and the counted waits of the loop carry no conditionals;
       // the loads are drained before the kernel ends.
       const char* cur = smem + st * STAGE;
       bf16x8_t a6[NA][2], b06[2 * BF0][2], b16[2][2];  // fragments: [16-row block][K-step of 32]
       // end of a phase: counted wait for the half-tile the next phase reads (+ the previous epilogue's stores while they are
-      // still counted), then the workgroup barrier
-      auto end_phase = [&](auto wtag) {
-        constexpr int W = decltype(wtag)::value;
-        wait_vm_sel<W, W + NS>(credit_i);
+      // still counted: credit 1 = all NS of them are younger than every load of this K-tile, credit 2 = the previous tile's epilogue
+      // was overlapped - `w2` says how many of its stores are younger than THIS wait's target), then the workgroup barrier
+      auto end_phase = [&](auto wtag, auto w2tag) {
+        constexpr int W = decltype(wtag)::value, W2 = decltype(w2tag)::value;
+        if (LASTOVL) wait_vm<W>();  // never the first K-tile of a tile (nk >= 2): no credit; W includes this K-tile's own unit stores
+        else if (OVL) wait_vm_sel3<W, W + NS, W + W2>(credit_i);
+        else wait_vm_sel<W, W + NS>(credit_i);
         phase_barrier();
       };
       using std::integral_constant;
+      auto slot_write = [&](auto sltag) {
+        constexpr int u = OP::unit_in_slot(decltype(sltag)::value);
+        if constexpr (LASTOVL && u >= 0) unit_write(integral_constant<int, (u >= 0 ? u : 0)>{});
+      };
+      auto slot_store = [&](auto sltag) {
+        constexpr int u = OP::unit_in_slot(decltype(sltag)::value);
+        if constexpr (LASTOVL && u >= 0) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          unit_store(integral_constant<int, (u >= 0 ? u : 0)>{}, std::true_type{}, m0, n0);
+        }
+      };
+      // cumulative unit stores in front of a wait of the overlapped K-tile: group 0 waits behind its phase's stores, group 1 in front
+      constexpr int S2 = LASTOVL ? OVS_2 : 0, S4 = LASTOVL ? OVS_2 + OVS_3 + OVS_4 : 0;
 
       // ---- phase 1: quadrant (A0, B0); stage A1 of the next K-tile, then move the cursor on
       issue_a(1, smem + s_st * STAGE, s_k);
@@ -377,14 +521,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
 #pragma unroll
         for (int f = 0; f < NA; ++f) a6[f][ks] = frag16(cur + OFF_A0, wm * AH + f * 16 + l15, ks);
       }
-      if (grp1) end_phase(integral_constant<int, D_P1>{});
+      if (grp1) end_phase(integral_constant<int, D_P1>{}, integral_constant<int, NS>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int j = 0; j < 2 * BF0; ++j) acc4[f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[f][j]);
-      if (!grp1) end_phase(integral_constant<int, D_P1>{});
+      if (!grp1) end_phase(integral_constant<int, D_P1>{}, integral_constant<int, NS>{});
 
       // ---- phase 2: quadrant (A0, B1); stage A0 two K-tiles ahead, into the slot phase 1 just read
       issue_a(0, smem + s_st * STAGE, s_k);
@@ -392,14 +536,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int c = 0; c < 2; ++c) b16[c][ks] = frag16(cur + OFF_B1, wn * 32 + c * 16 + l15, ks);
-      if (grp1) end_phase(integral_constant<int, D_P2>{});
+      slot_write(integral_constant<int, 2>{});
+      if (grp1) end_phase(integral_constant<int, D_P2>{}, integral_constant<int, NS>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[f][2 * BF0 + c]);
-      if (!grp1) end_phase(integral_constant<int, D_P2>{});
+      slot_store(integral_constant<int, 2>{});
+      if (!grp1) end_phase(integral_constant<int, D_P2 + S2>{}, integral_constant<int, NS>{});
 
       // ---- phase 3: quadrant (A1, B1); stage B0.  Phase 4 reads nothing new from LDS, so no vmcnt wait is due here.
       issue_b(0, smem + s_st * STAGE, s_k);
@@ -407,26 +553,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NA; ++f) a6[f][ks] = frag16(cur + OFF_A1, wm * AH + f * 16 + l15, ks);
-      if (grp1) end_phase(integral_constant<int, D_P4 - B1_DMA>{});  // B1'' is only issued in phase 4
+      slot_write(integral_constant<int, 3>{});
+      // B1'' is only issued in phase 4.  First K-tile behind an overlapped epilogue: the B0 half-tile this wait is for was issued behind the
+      // phase-2 unit's stores of that tile
+      if (grp1) end_phase(integral_constant<int, D_P4 - B1_DMA + S2>{}, integral_constant<int, NS - OVS_2>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc4[NA + f][2 * BF0 + c] = mfma16(b16[c][ks], a6[f][ks], acc4[NA + f][2 * BF0 + c]);
+      slot_store(integral_constant<int, 3>{});
 
       // ---- phase 4: quadrant (A1, B0) (B0 fragments still in registers); stage B1
       issue_b(1, smem + s_st * STAGE, s_k);
+      slot_write(integral_constant<int, 4>{});
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NA; ++f)
 #pragma unroll
           for (int j = 0; j < 2 * BF0; ++j) acc4[NA + f][j] = mfma16(b06[j][ks], a6[f][ks], acc4[NA + f][j]);
-      if (!grp1) end_phase(integral_constant<int, D_P4>{});
+      slot_store(integral_constant<int, 4>{});
+      if (!grp1) end_phase(integral_constant<int, D_P4 + S4>{}, integral_constant<int, NS - OVS_2>{});
       credit = false;
       credit_i = 0;
       st ^= 1;
+    };
+
+    // plain schedule: an interior tile with at least two K-tiles runs its last K-tile in the overlapped form; the tile origin is
+    // computed where it is needed (and again for the epilogue) so that it stays out of the K loop's live registers
+    bool ovl = false;
+    if (OVL) {
+      Cur peek = cc;
+      int pm0, pn0, pk0, pk1, psp;
+      take(peek, pm0, pn0, pk0, pk1, psp);
+      ovl = __builtin_amdgcn_readfirstlane(nk >= 2 && alpha_dev == nullptr && pm0 + BM <= M && pn0 + BN <= N);  // every wave issues exactly the counted stores
+    }
+    {
+      const int nloop = ovl ? nk - 1 : nk;
+      for (int kt = 0; kt < nloop; ++kt) ktile(std::false_type{}, 0, 0);
+    }
+    if (OVL && ovl) {
+      Cur peek = cc;
+      int pm0, pn0, pk0, pk1, psp;
+      take(peek, pm0, pn0, pk0, pk1, psp);
+      ktile(std::true_type{}, pm0, pn0);
     }
 
     if (!HYB) take(cc, m0, n0, kbeg, kend, split);
@@ -457,6 +629,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const uint16_t* __r
       for (int i = 0; i < 2 * NA; ++i)
 #pragma unroll
         for (int j = 0; j < 2 * NBF; ++j) acc4[i][j] *= alpha;
+    }
+    if constexpr (OVL) {
+      // plain epilogue, unit by unit; after an overlapped last K-tile only the units that became final in its fourth phase are left
+      auto drain = [&](auto utag) {
+        constexpr int u = decltype(utag)::value;
+        if (ovl && OP::slot(u) != 5) return;
+        unit_write(utag);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unit_store(utag, std::false_type{}, m0, n0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      nt_for_units(drain, std::make_integer_sequence<int, NUNIT>{});
+      credit = m0 + BM <= M && n0 + BN <= N;  // interior tile: every wave issued exactly NS stores
+      credit_i = __builtin_amdgcn_readfirstlane(credit ? (ovl ? 2 : 1) : 0);
+      continue;
     }
 #pragma unroll
     for (int mf = 0; mf < NA; ++mf) {  // 32-row pieces = the 16-row blocks 2 mf, 2 mf + 1 of acc4 (block f holds rows f * 16 ... of the wave tile)

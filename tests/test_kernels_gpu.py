@@ -487,6 +487,24 @@ def test_short_batch_tile_128x192(ops):
     assert torch.equal(got, two), (B_, T, nh, K)
 
 
+@pytest.mark.parametrize('variant', [4, 5, 6, 7])
+def test_overlapped_epilogue_exact(ops, variant):
+  """Round 5: in the last K-tile of an interior tile the persistent NT kernels hand finished accumulator quadrants to the epilogue while
+  the other quadrants are still being multiplied (csrc/gemm_big.hip, OVL), with the stores counted into the LDS-DMA ring's vmcnt waits - of
+  that K-tile and of the next tile's first one.  A miscounted wait reads a half-tile that has not landed: exactness on integer-valued
+  operands (fp32 sums exact in any order, one bf16 rounding) against the device's fp32 matmul, for two K-tiles (first K-tile directly in
+  front of the overlapped one), many, one (no overlap), edge tiles in M and N, 1 - 4 tiles per workgroup, three runs each."""
+  g = torch.Generator(device='cuda').manual_seed(50 + variant)
+  for M, N, K in ((32768, 768, 768), (9000, 1160, 128), (65536, 768, 192), (4096, 4096, 2048), (16384, 1024, 64), (33000, 2304, 320)):
+    A = bf(torch.randint(-2, 3, (M, K), generator=g, device='cuda').float())
+    B = bf(torch.randint(-2, 3, (N, K), generator=g, device='cuda').float())
+    ref = (A.float() @ B.float().t()).to(torch.bfloat16)
+    for _ in range(3):
+      out = ops.gemm_nt(A, B, variant=variant)
+      assert torch.equal(out, ref), (variant, M, N, K, (out.float() - ref.float()).abs().max().item())
+    del A, B, ref, out
+
+
 def test_fused_entry_points_fall_back_under_gemm_v1(ops, plm_env):
   """PLM_GEMM_V1=1 forces the register-staged 128x128 GEMMs: the three entry points with fused epilogues must then take their
   two-launch paths (the backward one asks for its d(act) scratch with PLM_E_WORKSPACE and gets it) and still be right."""
