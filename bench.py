@@ -463,7 +463,7 @@ def main():
     local_ms = []
     for alt in alts:
       apply_alt(alt)
-      for i in range(2):
+      for i in range(ddp.FREEZE_AFTER + 1):  # the reserve windows are learned and frozen (one host wait + one agreement) before the clock starts
         fwd_bwd(i)
       torch.cuda.synchronize()
       t0 = time.perf_counter()

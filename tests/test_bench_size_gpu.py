@@ -50,8 +50,24 @@ def rel_l2(a, ref):
   return ((a - ref).norm() / ref.norm().clamp_min(1e-30)).item()
 
 
-L2_TOL_FP32 = 1.0  # fitted below
-L2_TOL_EMU = 1.0
+PROJ_TOL = 4e-3  # measured 1.1e-3 (fp32 oracle, batch 32) / 9.7e-4 (emulating oracle, 16 x pair)
+
+
+def _l2_report(tag, got, ref, tol_norm, tol_rest):
+  """Relative L2 error per tensor, bounded per class (RMSNorm weights / everything else); prints the worst of each class."""
+  l2 = {n: rel_l2(got[n], ref[n]) for n in got}
+  wn = max((e, n) for n, e in l2.items() if 'norm' in n)
+  wr = max((e, n) for n, e in l2.items() if 'norm' not in n)
+  print(f'{tag} (relative L2): worst norm weight {wn[1]} {wn[0]:.1e}, worst other {wr[1]} {wr[0]:.1e}')
+  bad = {n: e for n, e in l2.items() if e > (tol_norm if 'norm' in n else tol_rest)}
+  assert not bad, bad
+  # The noise floor above is rounding noise with no preferred direction; a SYSTEMATIC error (a wrong scale, a missing term) moves the
+  # projection of the gradient onto the oracle's, <g, ref> / <ref, ref>, away from 1 by its full size while noise of relative size s
+  # moves it by ~ s / sqrt(numel): the bound that makes a kernel "1e-2 wrong on a norm-weight gradient" fail at full size
+  proj = {n: (got[n].double().flatten() @ ref[n].double().flatten() / (ref[n].double().flatten() @ ref[n].double().flatten())).item() for n in got}
+  wp = max((abs(c - 1.0), n) for n, c in proj.items())
+  print(f'{tag} (projection coefficient): worst |c - 1| = {wp[0]:.1e} ({wp[1]})')
+  assert wp[0] <= PROJ_TOL, wp
 
 
 def _random_docs(B, T, seed, mean_len=256):
@@ -252,11 +268,9 @@ def test_160m_batch32_loss_and_all_gradients_vs_oracle(ops):
   # rel-to-max is the error of the single noisiest element, and at this size every gradient sits at 1-2e-2 of bf16 rounding noise against
   # the FP32 oracle (norm weights 2.1e-2, fc1 1.7e-2): a kernel that is systematically 1e-2 off would hide under it.  The
   # relative L2 error averages the noise and keeps a systematic error whole: bounded per tensor as well
-  l2 = {n: rel_l2(got[n], og[n]) for n in got}
-  top = sorted(l2.items(), key=lambda kv: -kv[1])[:5]
-  print('160M batch-32 gradients vs fp32 oracle (relative L2), worst five:', [(n, f'{e:.1e}') for n, e in top])
-  bad = {n: e for n, e in l2.items() if e > L2_TOL_FP32}
-  assert not bad, bad
+  # measured: norm weights 1.6e-2 (at init their gradient is a small sum of 32768 large cancelling terms: the rounding noise of the terms
+  # does not shrink with it), Linear / embedding weights below that
+  _l2_report('160M batch-32 gradients vs fp32 oracle', got, og, 3e-2, 2.5e-2)
 
 
 def test_160m_batch32_launch_vs_bf16_emulating_oracle(ops):
@@ -296,8 +310,4 @@ def test_160m_batch32_launch_vs_bf16_emulating_oracle(ops):
   # 5e-3 needs its 2 layers), relative L2 an order of magnitude below the fp32 comparison's
   bad = {n: e for n, e in worst.items() if e > 2.5e-2}
   assert not bad, bad
-  l2 = {n: rel_l2(got[n], eg[n]) for n in got}
-  top = sorted(l2.items(), key=lambda kv: -kv[1])[:5]
-  print('160M 16 x pair gradients vs bf16-emulating oracle (relative L2), worst five:', [(n, f'{e:.1e}') for n, e in top])
-  bad = {n: e for n, e in l2.items() if e > L2_TOL_EMU}
-  assert not bad, bad
+  _l2_report('160M 16 x pair gradients vs bf16-emulating oracle', got, eg, 2.5e-2, 2e-2)

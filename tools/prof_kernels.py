@@ -61,6 +61,13 @@ def main():
     del Um
     if lib.plm_gemm_nt_workspace_bytes(m, n, k) > 0:
       entry(name + ' (stream-K reduce)', 'nt_streamk_reduce', 0.0, 0.0, M=m, N=n, K=k, part_of=name)
+    if name == 'nt head fwd':
+      # the same launch on 256x128 tiles - an XCD's 32-tile rectangle then needs 4 A + 8 B half-panels = 3.1 MB (fits the
+      # 4 MB L2) instead of 4.7 MB; reported beside the shipped 256x256 launch (traffic / algorithmic and, in kbench --variants, its time)
+      for _ in range(2):
+        ops.gemm_nt(A, Bm, out=out, variant=6)
+      torch.cuda.synchronize()
+      entry('nt head fwd [256x128 tiles, not shipped]', 'gemm_nt', 2.0 * m * n * k, alg, M=m, N=n, K=k)
     del A, Bm, out
   for name, (m, n, k) in TN.items():
     A = torch.randn(k, m, device='cuda').to(BF)
