@@ -1401,10 +1401,12 @@ bool plm_nt_hybrid_plan(int64_t M, int64_t N, int64_t K, NtHybridPlan* p) {
   }
   if (plm_env().nt_no_hybrid) return false;
   const bool mk = plm_env().nt_hybrid_min_k >= 0;  // tests / A-B runs lower the thresholds
-  // measured (profiles/r01_kbench_run18*): the fp32 slab traffic (~40 us) only pays off for long K - on the whole chip.  With CUs set
-  // aside for RCCL (240 slots) every plain tiling of the N = 768 shapes loses 20 % to round quantisation and the hybrid pays from
-  // K = 2048 (run 38: +0.4 % end to end under a 16-CU reserve)
-  const int64_t min_k = mk ? plm_env().nt_hybrid_min_k : (g_cu_reserve > 0 ? 2048 : 8192), min_l = mk ? 2 : 8;
+  // measured (profiles/r01_kbench_run18*): the fp32 slab traffic (~40 us) only pays off for long K.  Round 3 lowered the threshold to 2048
+  // while CUs are reserved for RCCL because the plain alternative was then the 128x128 kernel (the 0.85 cliff); with the shared tile policy
+  // the alternative is the persistent 256x256 kernel on two ragged rounds, which beats the hybrid at K = 2048 ... 4096 under an 8- and a
+  // 16-CU reserve (profiles/r05_kbench_variants.txt: fc2 fwd 97 vs 115 us, dX qkv 108 vs 134, dX fc1 187 vs 197) - only lm_head's dX
+  // (K = 50304) still gains (2004 vs 2089 us under 16 reserved CUs)
+  const int64_t min_k = mk ? plm_env().nt_hybrid_min_k : 8192, min_l = mk ? 2 : 8;
   if (K % 64 != 0 || N % 8 != 0 || M < 2048 || N < 256 || K < min_k) return false;
   const int slots = persistent_slots();
   const int64_t R = plm_cdiv(M, 256), Cn = plm_cdiv(N, 256), tiles = R * Cn, nkt = K / 64;
