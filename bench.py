@@ -409,7 +409,7 @@ def main():
       o['data'] = 'synthetic; PLUMBING CHECK ONLY: all ranks share cuda:0, gradients over gloo - not a throughput measurement'
     return o
 
-  def comm_info(alt, per_rank, extra=None):
+  def comm_info(alt, per_rank, extra=None, stats=None):
     reducer = st['reducer']
     info = {'backend': reducer.comm.backend, 'ranks': reducer.comm.world_size, 'buckets': len(reducer.buckets),
             'bucket_cap_mb': a.bucket_mb, 'selected': alt, 'cu_reserve': reducer.reserve_cus,
@@ -422,19 +422,20 @@ def main():
             'rank_ms_per_step': {'min': round(1e3 * min(per_rank) / a.steps, 3), 'max': round(1e3 * max(per_rank) / a.steps, 3)},
             'n1_ms_per_step': round(n1_ms, 3) if n1_ms is not None else None,
             'n1_note': 'rank 0 alone (no data plane, same process, before any communicator existed), same warm-up / steps'}
-    info.update(reducer.stats())  # bucket_ms, exposed_comm_ms (the join wait of the last step), clock scale, share of MFMA launches that ran reserved
+    info.update(stats or reducer.stats())  # of the timed run: bucket_ms, exposed_comm_ms (the join wait of its last step), clock scale, share of MFMA launches that ran reserved
     if extra:
       info.update(extra)
     return info
 
   out = line(elapsed, last_loss)
+  run_stats = st['reducer'].stats() if ddp_on else None  # before any re-configuration resets what the reducer has learned
   if ddp_on:
     if n1_ms is not None:
       tt = torch.tensor([n1_ms], dtype=torch.float64)
       if world > 1:
         dist.broadcast(tt, src=0)
       n1_ms = float(tt.item())
-    out['comm'] = comm_info(alt_default, per_rank)
+    out['comm'] = comm_info(alt_default, per_rank, stats=run_stats)
 
   # ---- data-parallel autotune (untimed): every alternative of {all-reduce, reduce-scatter + all-gather} x {no reserve, 8, 16 CUs}
   # x {tail bucket on the capped communicator, on the uncapped root} for a few steps each; the ranks agree on the winner (the
@@ -482,10 +483,12 @@ def main():
       if e2 < elapsed:
         elapsed, per_rank, last_loss, chosen = e2, pr2, l2, alts[win]
         out = line(elapsed, last_loss)
+        run_stats = st['reducer'].stats()
     if chosen == alt_default:
-      apply_alt(alt_default)
+      apply_alt(alt_default)  # the untimed legs below run on the selected data plane
     out['comm'] = comm_info(chosen, per_rank, {'alternatives': table, 'timed_runs': runs,
-                                               'autotune': f'{len(alts)} alternatives x {n_try} steps (max over ranks, agreed); value = the better of the full timed runs'})
+                                               'autotune': f'{len(alts)} alternatives x {n_try} steps (max over ranks, agreed); value = the better of the full timed runs'},
+                            stats=run_stats)
     dog.cancel()
   ms_per_step = out['ms_per_step']
   reducer = st['reducer']
