@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of environment settings inside the training step:  gpurun -- 'bash tools/ab_env.sh 2 "" "PLM_NT_DUO=1" "PLM_NT_DUO=1 PLM_DUO_STAGGER_US=9"'
+# Same-box A/B of environment settings inside the training step:  gpurun -- 'bash tools/ab_env.sh 2 "" "PLM_NT_NO_HYBRID=1" "PLM_HEAD_CHUNK=16384"'
 # Prints tokens/s of `bench.py --steps 20 --warmup 5 --no-extras` for every setting, N rounds, interleaved.
 N=$1; shift
 cd "$(dirname "$0")/.."

@@ -1,3 +1,7 @@
+#!/bin/bash
+# Kernel trace of bench.py with and without the 1-rank data plane (PLM_FORCE_REDUCER=1, no reserve):  gpurun -- 'bash tools/ddp_trace.sh'
+# -> gpurun_out/r05d/trace_plain.txt, trace_reducer_cap0.txt (profiles/r05_ddp_trace_1gpu.txt is their digest).  The environment is exported in THIS shell:
+# nothing but the program itself may stand behind rocprofv3's "--".
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05d; mkdir -p $O
 summ() {
