@@ -368,13 +368,14 @@ def main():
 
   comms, alt_default = None, None
   if ddp_on:
-    # the communicator set: uncapped root + children capped at 8 / 16 workgroups (ncclCommSplit with maxCTAs); the default data plane
-    # is ddp.pick_comms' (PLM_COMM_CUS = 16 for the buckets reduced during backward, the exposed tail bucket through the root)
-    comms = ddp.make_comm_set(device, a.comm, caps=sorted({8, 16, ddp.COMM_CUS} - {0}))
-    comm, comm_tail, reserve = ddp.pick_comms(comms)
-    alt_default = {'algo': os.environ.get('PLM_COMM_ALGO') or 'allreduce', 'cap': reserve, 'tail': comm_tail is not None}
-    reducer = ddp.GradReducer(flat, params, model._grad_spans, comm, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
-                              reserve_cus=reserve, writers=model.grad_writers(), comm_tail=comm_tail, groups=model.grad_groups(),
+    # The contract's timed region runs on the SIMPLEST data plane - the uncapped root communicator (a plain ncclCommInitRank), ncclAllReduce,
+    # no CU reserve: the path least likely to fail in a first multi-GPU contact, so that whatever happens afterwards (ncclCommSplit, capped
+    # collectives, the other algorithm) a measurement exists.  The capped communicators are created and every alternative - including the
+    # engine's default, cap PLM_COMM_CUS = 16 with the tail bucket on the root - is measured afterwards, under a watchdog.
+    comms = ddp.make_comm_set(device, a.comm, caps=[])
+    alt_default = {'algo': os.environ.get('PLM_COMM_ALGO') or 'allreduce', 'cap': 0, 'tail': False}
+    reducer = ddp.GradReducer(flat, params, model._grad_spans, comms[0], bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
+                              reserve_cus=0, writers=model.grad_writers(), comm_tail=None, groups=model.grad_groups(),
                               algo=alt_default['algo'])
     reducer.broadcast_params([p.data for p in params])
     model.sink.on_ready = reducer.param_ready
@@ -437,58 +438,68 @@ def main():
       n1_ms = float(tt.item())
     out['comm'] = comm_info(alt_default, per_rank, stats=run_stats)
 
-  # ---- data-parallel autotune (untimed): every alternative of {all-reduce, reduce-scatter + all-gather} x {no reserve, 8, 16 CUs}
-  # x {tail bucket on the capped communicator, on the uncapped root} for a few steps each; the ranks agree on the winner (the
-  # alternative whose SLOWEST rank is fastest); if it is not the default it is then timed over the full `steps`, and the better of
-  # the two full timed regions is the line's value (both are reported).  A watchdog prints the default's line if any of this hangs.
+  # ---- data-parallel autotune (untimed): capped communicators (ncclCommSplit, maxCTAs 8 / 16), then every alternative of {all-reduce,
+  # reduce-scatter + all-gather} x {no reserve, 8, 16 CUs} x {tail bucket on the capped communicator, on the uncapped root} for a few steps
+  # each; the ranks agree on the winner (the alternative whose SLOWEST rank is fastest); if it is not the first one it is then timed over the
+  # full `steps`, and the better of the two full timed regions is the line's value (both are reported).  A watchdog prints the first
+  # region's line if any of this hangs, an exception does the same.
   if ddp_on and not a.no_autotune and os.environ.get('PLM_BENCH_AUTOTUNE', '1') != '0':
     import threading
     deadline = float(os.environ.get('PLM_BENCH_AUTOTUNE_TIMEOUT', '300'))
     def give_up():
-      out['comm']['autotune'] = f'did not finish within {deadline:.0f} s: this line is the default data plane\'s timed run'
+      out['comm']['autotune'] = f'did not finish within {deadline:.0f} s: this line is the timed run on the simplest data plane'
       if rank == 0:
         os.write(json_fd, (json.dumps(out) + '\n').encode())
       os._exit(0)
     dog = threading.Timer(deadline, give_up)
     dog.daemon = True
     dog.start()
-    direct = isinstance(comms[0], ddp.RcclComm)
-    alts = []
-    for algo in (('allreduce', 'rsag') if direct else ('allreduce',)):
-      for cap in (0, 8, 16):
-        for tail in ((False, True) if (cap and cap in comms) else (False,)):
-          alts.append({'algo': algo, 'cap': cap, 'tail': tail})
-    if alt_default not in alts:
-      alts.insert(0, alt_default)
-    n_try = int(os.environ.get('PLM_BENCH_AUTOTUNE_STEPS', '4'))
-    local_ms = []
-    for alt in alts:
-      apply_alt(alt)
-      for i in range(ddp.FREEZE_AFTER + 1):  # the reserve windows are learned and frozen (one host wait + one agreement) before the clock starts
-        fwd_bwd(i)
-      torch.cuda.synchronize()
-      t0 = time.perf_counter()
-      for i in range(n_try):
-        fwd_bwd(i)
-      torch.cuda.synchronize()
-      local_ms.append(1e3 * (time.perf_counter() - t0) / n_try)
-    win, agreed = ddp.agree_winner(local_ms)
-    table = [dict(alt, ms_per_step=round(ms, 3)) for alt, ms in zip(alts, agreed)]
-    runs = [dict(alt_default, ms_per_step=out['ms_per_step'], role='default')]
-    chosen = alt_default
-    if alts[win] != alt_default and agreed[win] < 0.995 * agreed[alts.index(alt_default)]:
-      apply_alt(alts[win])
-      e2, pr2, l2 = timed(max(2, ddp.FREEZE_AFTER + 1), a.steps)
-      runs.append(dict(alts[win], ms_per_step=round(1e3 * e2 / a.steps, 3), role='autotune winner'))
-      if e2 < elapsed:
-        elapsed, per_rank, last_loss, chosen = e2, pr2, l2, alts[win]
-        out = line(elapsed, last_loss)
-        run_stats = st['reducer'].stats()
-    if chosen == alt_default:
-      apply_alt(alt_default)  # the untimed legs below run on the selected data plane
-    out['comm'] = comm_info(chosen, per_rank, {'alternatives': table, 'timed_runs': runs,
-                                               'autotune': f'{len(alts)} alternatives x {n_try} steps (max over ranks, agreed); value = the better of the full timed runs'},
-                            stats=run_stats)
+    try:
+      ddp.add_capped_comms(comms, sorted({8, 16, ddp.COMM_CUS} - {0}))
+      direct = isinstance(comms[0], ddp.RcclComm)
+      alts = []
+      for algo in (('allreduce', 'rsag') if direct else ('allreduce',)):
+        for cap in (0, 8, 16):
+          for tail in ((False, True) if (cap and cap in comms) else (False,)):
+            alts.append({'algo': algo, 'cap': cap, 'tail': tail})
+      if alt_default not in alts:
+        alts.insert(0, alt_default)
+      n_try = int(os.environ.get('PLM_BENCH_AUTOTUNE_STEPS', '4'))
+      local_ms = []
+      for alt in alts:
+        apply_alt(alt)
+        for i in range(ddp.FREEZE_AFTER + 1):  # the reserve windows are learned and frozen (one host wait + one agreement) before the clock starts
+          fwd_bwd(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_try):
+          fwd_bwd(i)
+        torch.cuda.synchronize()
+        local_ms.append(1e3 * (time.perf_counter() - t0) / n_try)
+      win, agreed = ddp.agree_winner(local_ms)
+      table = [dict(alt, ms_per_step=round(ms, 3)) for alt, ms in zip(alts, agreed)]
+      runs = [dict(alt_default, ms_per_step=out['ms_per_step'], role='first timed region (simplest data plane)')]
+      chosen = alt_default
+      if alts[win] != alt_default and agreed[win] < 0.995 * agreed[alts.index(alt_default)]:
+        apply_alt(alts[win])
+        e2, pr2, l2 = timed(max(2, ddp.FREEZE_AFTER + 1), a.steps)
+        runs.append(dict(alts[win], ms_per_step=round(1e3 * e2 / a.steps, 3), role='autotune winner'))
+        if e2 < elapsed:
+          elapsed, per_rank, last_loss, chosen = e2, pr2, l2, alts[win]
+          out = line(elapsed, last_loss)
+          run_stats = st['reducer'].stats()
+      if chosen == alt_default:
+        apply_alt(alt_default)  # the untimed legs below run on the selected data plane
+      out['comm'] = comm_info(chosen, per_rank, {'alternatives': table, 'timed_runs': runs,
+                                                 'autotune': f'{len(alts)} alternatives x {n_try} steps (max over ranks, agreed); value = the better of the full timed runs'},
+                              stats=run_stats)
+    except Exception as e:  # noqa: BLE001 - the first timed region's line must survive whatever the alternatives do
+      import traceback
+      traceback.print_exc()
+      out['comm']['autotune'] = f'failed on rank {rank} ({type(e).__name__}: {e}): this line is the timed run on the simplest data plane'
+      if rank == 0:
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+      os._exit(0)  # the other ranks may be inside a collective: no clean shutdown to wait for
     dog.cancel()
   ms_per_step = out['ms_per_step']
   reducer = st['reducer']

@@ -507,8 +507,17 @@ def make_comm_set(device, backend=None, group=None, caps=None):
     # box whose RCCL set-up differs from the build machine still trains
     print(f'[plainlm_amd.ddp] rank {rank}: direct RCCL communicator unavailable ({err}); using torch.distributed nccl', flush=True)
     return {0: TorchDistComm(dist.new_group(backend='nccl'))}
-  comms = {0: root}
-  for cap in sorted({int(c) for c in caps if int(c) > 0}):
+  return add_capped_comms({0: root}, caps, group)
+
+
+def add_capped_comms(comms, caps, group=None):
+  """Add one ncclCommSplit child of the root per cap (ncclConfig_t.maxCTAs) to a make_comm_set; collective, a cap whose split fails on
+  any rank is left out on every rank.  bench.py calls it AFTER its first timed region: a run whose RCCL cannot split must not lose the
+  measurement on the root communicator."""
+  root = comms[0]
+  if not isinstance(root, RcclComm):
+    return comms
+  for cap in sorted({int(c) for c in caps if int(c) > 0} - set(comms)):
     child, err = None, None
     try:
       child = root.split(max_ctas=cap)
@@ -519,7 +528,7 @@ def make_comm_set(device, backend=None, group=None, caps=None):
     else:
       if child is not None:
         child.close()
-      print(f'[plainlm_amd.ddp] rank {rank}: no communicator capped at {cap} workgroups ({err}); that cap is not available', flush=True)
+      print(f'[plainlm_amd.ddp] rank {root.rank}: no communicator capped at {cap} workgroups ({err}); that cap is not available', flush=True)
   return comms
 
 
