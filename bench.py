@@ -354,7 +354,7 @@ def main():
   # ---- N = 1 reference inside the same run (data-parallel runs only): rank 0 alone, before any communicator exists, the others
   # wait at the barrier - the scaling efficiency of this line does not depend on a second run on another box / another day
   n1_ms = None
-  if ddp_on and not a.single_device:
+  if ddp_on:  # (also in the --single-device plumbing check: every rank-asymmetric stretch of this file runs in the 2-rank GPU test)
     if rank == 0:
       for i in range(a.warmup):
         fwd_bwd(i)
@@ -431,11 +431,7 @@ def main():
   out = line(elapsed, last_loss)
   run_stats = st['reducer'].stats() if ddp_on else None  # before any re-configuration resets what the reducer has learned
   if ddp_on:
-    if n1_ms is not None:
-      tt = torch.tensor([n1_ms], dtype=torch.float64)
-      if world > 1:
-        dist.broadcast(tt, src=0)
-      n1_ms = float(tt.item())
+    # (n1_ms lives on rank 0 only - the rank that prints; no collective here: the other ranks never measured it)
     out['comm'] = comm_info(alt_default, per_rank, stats=run_stats)
 
   # ---- data-parallel autotune (untimed): capped communicators (ncclCommSplit, maxCTAs 8 / 16), then every alternative of {all-reduce,

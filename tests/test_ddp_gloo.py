@@ -109,6 +109,23 @@ def _worker(rank, world, port, out_dir, tied=False):
   assert win == 0 and agreed[:2] == [2.0 + world - 1] * 2  # a tie goes to the lowest index on every rank
   # the one-off agreement on the reserve windows ('frozen' mode): the maximum over the ranks, elementwise
   assert ddp.agree_max_floats([0.001 * (rank + 1), 1.0 - 0.1 * rank]) == pytest.approx([0.001 * world, 1.0])
+  # bench.py's autotune switches the data plane between two steps (GradReducer.configure): same buckets, same result
+  if not tied:
+    before = flat_g.clone()
+    red.configure(comm=comm, comm_tail=None, reserve_cus=0, algo='rsag')  # torch.distributed data plane: the algorithm is RCCL-direct only
+    with pytest.raises(RuntimeError, match='inside a step'):
+      red.begin(sync=True)
+      red.configure(algo='allreduce')
+    red.sync = False
+    flat_g.copy_(before * (rank + 1))  # rank-dependent gradients: the mean over ranks is before * (world + 1) / 2
+    n0 = calls['n']
+    red.begin(sync=True)
+    for i in range(len(names) - 1, -1, -1):
+      red.param_ready(plist[i])
+    red.finish()
+    assert calls['n'] - n0 == len(red.buckets)
+    assert torch.allclose(flat_g, before * (world + 1) / 2, rtol=1e-6, atol=1e-9)
+    flat_g.copy_(before)
   torch.save({'params': flat_p.clone(), 'grads': flat_g.clone()}, os.path.join(out_dir, f'r{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()

@@ -192,6 +192,9 @@ def test_bench_two_ranks_on_one_device():
   out = json.loads(lines[0])
   assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
   assert out['comm']['ranks'] == 2 and out['comm']['buckets'] >= 2
+  # the data-parallel line measures its own N = 1 (rank 0 alone, before the data plane exists) and tunes its data plane by consensus
+  assert out['comm']['n1_ms_per_step'] > 0 and len(out['comm']['alternatives']) >= 3 and out['comm']['timed_runs'][0]['role'].startswith('first timed region')
+  assert out['comm']['rank_ms_per_step']['min'] <= out['comm']['rank_ms_per_step']['max'] and out['comm']['exposed_comm_ms'] is not None
   assert out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
   assert 'PLUMBING CHECK ONLY' in out['data']
   assert out['value'] > 0 and np.isfinite(out['loss']) and 10.0 < out['loss'] < 12.0  # ln(50280) = 10.83 at init
