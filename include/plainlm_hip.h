@@ -244,14 +244,16 @@ int plm_comm_init(plm_comm_t** comm, const uint8_t uid[128], int rank, int world
  * max_ctas <= 0: RCCL's default).  Gradient buckets reduced WHILE backward is still running go through a capped
  * communicator (the persistent GEMMs leave exactly that many CUs free, plm_set_cu_reserve), the buckets that become ready
  * when backward has ended - embed_tokens, 154 MB, ready last: engine/engine.py:104-105 leaves it exposed too - go through
- * an uncapped one obtained with plm_comm_split: with nothing left to overlap with, the tail should use every xGMI link. */
+ * an uncapped one: with nothing left to overlap with, the tail should use every xGMI link.  The host side (plainlm_amd/ddp.py,
+ * round 5) creates the UNCAPPED communicator first (plm_comm_init) and splits the capped ones off it (plm_comm_split). */
 int plm_comm_init_capped(plm_comm_t** comm, const uint8_t uid[128], int rank, int world_size, int device, int max_ctas);
 /* ncclCommSplit of `parent` into a communicator over the same ranks with its own CTA cap (collective over parent's ranks). */
 int plm_comm_split(plm_comm_t* parent, plm_comm_t** child, int max_ctas);
 int plm_comm_destroy(plm_comm_t* comm);
 /* in-place all-reduce-mean of a fp32 span on `stream` (the side stream owned by the caller) */
 int plm_comm_allreduce_avg_f32(plm_comm_t* comm, float* buf, int64_t count, void* stream);
-/* the same mean as reduce-scatter + all-gather in place (one-hop collectives over all xGMI links; opt-in, PLM_COMM_ALGO=rsag) */
+/* the same mean as reduce-scatter + all-gather in place (one-hop collectives over all xGMI links; the reducer's `algo` choice -
+ * PLM_COMM_ALGO=rsag, or bench.py's autotune) */
 int plm_comm_rsag_avg_f32(plm_comm_t* comm, float* buf, int64_t count, void* stream);
 int plm_comm_broadcast_f32(plm_comm_t* comm, float* buf, int64_t count, int root, void* stream);
 
