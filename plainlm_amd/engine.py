@@ -109,17 +109,14 @@ def intialize_optimizer(param_groups, cfg, model=None):
 def doc_start_from_lengths(docs_lengths, seq_len):
   """Host prefix sums: for every token the index of its document's first token, int32 [B, T].
   Equivalent to the mask of data_prep_utils.py:7-23 cropped at engine.py:23 (lengths sum to T+1)."""
-  rows = []
-  for lens in docs_lengths:
-    lens = [int(v) for v in lens]
-    if sum(lens) != seq_len + 1:
+  out = np.empty((len(docs_lengths), seq_len), dtype=np.int32)
+  for r, lens in enumerate(docs_lengths):
+    lens = np.asarray([int(v) for v in lens], dtype=np.int64)
+    if int(lens.sum()) != seq_len + 1:
       raise ValueError('Sum of doc_boundaries does not match max_seq_length.')
-    row, start = [], 0
-    for n in lens:
-      row.extend([start] * n)
-      start += n
-    rows.append(row[:seq_len])
-  return torch.tensor(rows, dtype=torch.int32)
+    starts = np.cumsum(lens) - lens                      # first token of every document
+    out[r] = np.repeat(starts, lens)[:seq_len]           # one vectorised expansion per row (was a Python list of T ints per row)
+  return torch.from_numpy(out)
 
 
 class _Stager:
