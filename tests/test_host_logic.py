@@ -315,6 +315,7 @@ def test_no_register_spills_in_the_persistent_gemm_kernels():
   spills (+30 % on every hybrid launch of a data-parallel run) and nobody looked: the kernel was still correct.  Compile
   csrc/gemm_big.hip with the library's flags (hipcc cross-compiles without a GPU) and require: no VGPR / SGPR spill and no scratch in
   any persistent GEMM kernel, and no draining `s_waitcnt vmcnt(0)` inside the K loops of the plain NT kernels."""
+  import ast
   import re
   import subprocess
   import sys
@@ -325,7 +326,7 @@ def test_no_register_spills_in_the_persistent_gemm_kernels():
   kernels = {}
   for i, l in enumerate(lines):
     if l.startswith('void gemm_') or l.startswith('gemm_'):
-      meta = eval(lines[i + 1].strip())  # the dict isa_scan prints
+      meta = ast.literal_eval(lines[i + 1].strip())  # the dict isa_scan prints
       kernels[l.strip()] = (meta, lines[i + 2] if i + 2 < len(lines) else '')
   big = {k: v for k, v in kernels.items() if 'gemm_nt_big_kernel' in k or 'gemm_tn_big_kernel' in k}
   assert len(big) >= 12, sorted(kernels)
