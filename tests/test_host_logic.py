@@ -342,3 +342,32 @@ def test_no_register_spills_in_the_persistent_gemm_kernels():
     if 'gemm_nt_big_kernel' in k and k.endswith('false, false, false, false>'):  # plain and HYB instantiations: the K loop never drains the DMA ring
       m = re.search(r'unconditional vmcnt\(0\): (\d+)', span)
       assert m and int(m.group(1)) <= 1, (k, span)
+
+
+@pytest.mark.timeout(900)
+def test_register_budget_of_the_attention_and_128x128_gemm_kernels():
+  """The same guard for the other MFMA files: no spill / scratch in any attention backward kernel, document-mask kernel or 128 x 128 GEMM; the causal
+  forward kernel is known to park 3 VGPRs and 14 SGPRs at its loop transitions (rounds 3-5: measured, outside the tile loops) - pinned at that, so
+  a fourth one is noticed."""
+  import ast
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  seen = 0
+  for f in ('attn_causal.hip', 'attn.hip', 'gemm.hip'):
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'isa_scan.py'), f], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    for i, l in enumerate(lines):
+      if i + 1 < len(lines) and lines[i + 1].strip().startswith("{'vgpr'"):
+        meta = ast.literal_eval(lines[i + 1].strip())
+        name = l.strip()
+        if 'attn' not in name and 'gemm' not in name:
+          continue
+        seen += 1
+        if 'attn_fwd_causal_kernel' in name:
+          assert meta['vspill'] <= 3 and meta['sspill'] <= 14 and meta['scratch'] <= 16, (name, meta)
+        else:
+          assert meta['vspill'] == 0 and meta['sspill'] == 0 and meta['scratch'] == 0, (name, meta)
+  assert seen >= 18, seen
+
