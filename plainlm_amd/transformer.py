@@ -347,11 +347,13 @@ class Transformer(nn.Module):
     _, y = Fn.AddNormFn.apply(h, branch, self.out_norm.weight, self.out_norm)
     return y, B, T
 
-  def forward(self, x, attn_mask=None):
+  @torch.compiler.disable  # engine/engine.py:68-70 may wrap the model in torch.compile: the kernels are hand-written, there is nothing to trace -
+  def forward(self, x, attn_mask=None):  # the compiled module runs this forward as it is (same bits), instead of graph-breaking on every ctypes call
     """inputs int64 [B,T], attn_mask -> bf16 logits [B,T,V] (models/transformer.py:108-114)."""
     y, B, T = self._trunk(x, attn_mask)
     return self.lm_head(y).view(B, T, self.cfg.vocab_size)
 
+  @torch.compiler.disable
   def loss(self, x, targets, attn_mask=None):
     """Mean token cross-entropy (fp32 scalar) with lm_head + CE fused (never keeps fp32 logits)."""
     y, B, T = self._trunk(x, attn_mask)

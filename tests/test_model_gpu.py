@@ -130,6 +130,23 @@ def test_reference_style_loss_path(P, mdl):
     assert relmax(p.grad, mdl['g:' + n]) < 4e-2, n
 
 
+def test_model_survives_torch_compile(P, mdl):
+  """the module 'must survive being wrapped by DDP(...) and (optionally) torch.compile' - engine/engine.py:68-70 compiles the
+  model when cfg.torch_compile is set (config/config.yaml:26, tr_420M_x8gpu.yaml:27).  There is nothing for a tracing compiler to do here: forward and
+  loss are marked torch.compiler.disable, so the compiled module runs the same kernels and returns the same bits, forward and backward."""
+  m = _small(P, mdl)
+  tok = mdl['tokens']
+  ids, tgt = tok[:, :64].cuda(), tok[:, 1:65].reshape(-1).cuda()
+  eager = m(ids, None)
+  cm = torch.compile(m)
+  logits = cm(ids, None)
+  assert torch.equal(logits, eager)
+  loss = torch.nn.CrossEntropyLoss()(logits.float().view(-1, 256), tgt)
+  loss.backward()
+  for n, p in m.named_parameters():
+    assert relmax(p.grad, mdl['g:' + n]) < 4e-2, n
+
+
 @pytest.mark.parametrize('chunk', [32, 48])
 def test_chunked_head_loss_matches_whole_logits_path(P, mdl, chunk):
   """loss() with the lm_head + cross-entropy walked in row chunks (the [M, V] logits never exist)
