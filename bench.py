@@ -384,8 +384,7 @@ def main():
     st['reducer'] = reducer
 
   def apply_alt(alt):
-    c, t, r = ddp.pick_comms(comms, cap=alt['cap'], tail=alt['tail'])
-    st['reducer'].configure(comm=c, comm_tail=t, reserve_cus=r, algo=alt['algo'])
+    ddp.apply_alternative(st['reducer'], comms, alt)
 
   # ---- the timed region of the contract (for a data-parallel run: on the DEFAULT data plane)
   elapsed, per_rank, last_loss = timed(a.warmup, a.steps)
@@ -451,28 +450,16 @@ def main():
     dog.daemon = True
     dog.start()
     try:
-      ddp.add_capped_comms(comms, sorted({8, 16, ddp.COMM_CUS} - {0}))
-      direct = isinstance(comms[0], ddp.RcclComm)
-      alts = []
-      for algo in (('allreduce', 'rsag') if direct else ('allreduce',)):
-        for cap in (0, 8, 16):
-          for tail in ((False, True) if (cap and cap in comms) else (False,)):
-            alts.append({'algo': algo, 'cap': cap, 'tail': tail})
-      if alt_default not in alts:
-        alts.insert(0, alt_default)
       n_try = int(os.environ.get('PLM_BENCH_AUTOTUNE_STEPS', '4'))
-      local_ms = []
-      for alt in alts:
-        apply_alt(alt)
-        for i in range(ddp.FREEZE_AFTER + 1):  # the reserve windows are learned and frozen (one host wait + one agreement) before the clock starts
-          fwd_bwd(i)
-        torch.cuda.synchronize()
+
+      def run_steps(n):
         t0 = time.perf_counter()
-        for i in range(n_try):
+        for i in range(n):
           fwd_bwd(i)
         torch.cuda.synchronize()
-        local_ms.append(1e3 * (time.perf_counter() - t0) / n_try)
-      win, agreed = ddp.agree_winner(local_ms)
+        return time.perf_counter() - t0
+
+      alts, agreed, win = ddp.autotune(st['reducer'], comms, run_steps, first=alt_default, n_try=n_try, caps=sorted({8, 16, ddp.COMM_CUS} - {0}))
       table = [dict(alt, ms_per_step=round(ms, 3)) for alt, ms in zip(alts, agreed)]
       runs = [dict(alt_default, ms_per_step=out['ms_per_step'], role='first timed region (simplest data plane)')]
       chosen = alt_default

@@ -586,3 +586,42 @@ def agree_winner(local_ms, group=None):
   agreed = agree_max_floats(local_ms, group)
   best = min(range(len(agreed)), key=lambda i: (agreed[i], i))
   return best, agreed
+
+
+def apply_alternative(reducer, comms, alt):
+  """Put a GradReducer on one data-plane alternative {'algo', 'cap', 'tail'} of a make_comm_set (between two steps)."""
+  comm, comm_tail, reserve = pick_comms(comms, cap=alt['cap'], tail=alt['tail'])
+  reducer.configure(comm=comm, comm_tail=comm_tail, reserve_cus=reserve, algo=alt['algo'])
+
+
+def data_plane_alternatives(comms, first=None):
+  """The alternatives bench.py's autotune measures on a communicator set: {all-reduce, reduce-scatter + all-gather} (direct RCCL only) x
+  {no reserve, 8, 16 CUs} x {tail buckets on the capped communicator, on the uncapped root} (only where the set has that cap); `first`
+  (the data plane already timed) is kept / put in front."""
+  direct = isinstance(comms[0], RcclComm)
+  alts = []
+  for algo in (('allreduce', 'rsag') if direct else ('allreduce',)):
+    for cap in (0, 8, 16):
+      for tail in ((False, True) if (cap and cap in comms) else (False,)):
+        alts.append({'algo': algo, 'cap': cap, 'tail': tail})
+  if first is not None and first not in alts:
+    alts.insert(0, first)
+  return alts
+
+
+def autotune(reducer, comms, run_steps, first=None, n_try=4, caps=(8, 16), group=None):
+  """Measure every data-plane alternative for a few steps and agree on the winner.  Collective: every rank calls it at the same point
+  with the same arguments.  run_steps(n) runs n whole steps (begin ... finish through `reducer`), waits for them, and returns the
+  seconds they took on THIS rank.  Per alternative: FREEZE_AFTER + 1 untimed steps (the reserve windows are learned and frozen - one host
+  wait and one agreement - before the clock starts), then n_try timed ones.  Returns (alternatives, agreed ms per step = the slowest
+  rank's, index of the winner); the reducer is left on the LAST alternative - the caller applies the one it wants."""
+  add_capped_comms(comms, caps, group)
+  alts = data_plane_alternatives(comms, first)
+  local_ms = []
+  for alt in alts:
+    apply_alternative(reducer, comms, alt)
+    run_steps(FREEZE_AFTER + 1)
+    local_ms.append(1e3 * run_steps(n_try) / n_try)
+  win, agreed = agree_winner(local_ms, group)
+  return alts, agreed, win
+

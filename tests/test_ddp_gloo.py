@@ -126,6 +126,30 @@ def _worker(rank, world, port, out_dir, tied=False):
     assert calls['n'] - n0 == len(red.buckets)
     assert torch.allclose(flat_g, before * (world + 1) / 2, rtol=1e-6, atol=1e-9)
     flat_g.copy_(before)
+    # ddp.autotune - the loop bench.py --gpus N runs after its first timed region: every alternative gets FREEZE_AFTER + 1 untimed and n_try
+    # timed steps through the reducer (real collectives here), and the ranks leave with the SAME winner although each prefers another one
+    calls_rs, fake = {'n': 0}, {0: (5.0, 1.0, 0.5, 0.2), 1: (3.0, 3.5, 3.2, 3.4), 2: (2.0, 4.0, 3.9, 3.0)}  # alternative -> ms per step seen by rank 0, 1, 2, 3
+
+    def run_steps(n):
+      for _ in range(n):
+        red.begin(sync=True)
+        for i in range(len(names) - 1, -1, -1):
+          red.param_ready(plist[i])
+        red.finish()
+      k = calls_rs['n']
+      calls_rs['n'] += 1
+      return n * 1e-3 * fake[k // 2][rank]  # calls 2a and 2a + 1 belong to alternative a (warm-up, timed)
+
+    comms = {0: comm}
+    first = {'algo': 'allreduce', 'cap': 0, 'tail': False}
+    n0 = calls['n']
+    alts, agreed, win = ddp.autotune(red, comms, run_steps, first=first, n_try=2)
+    assert alts == [first, {'algo': 'allreduce', 'cap': 8, 'tail': False}, {'algo': 'allreduce', 'cap': 16, 'tail': False}]  # no caps / algorithms without direct RCCL
+    want = [max(fake[a_][:world]) for a_ in range(3)]
+    assert agreed == pytest.approx(want) and win == want.index(min(want)) == 1, (agreed, win)
+    assert calls_rs['n'] == 6 and calls['n'] - n0 == 3 * (ddp.FREEZE_AFTER + 1 + 2) * len(red.buckets)
+    ddp.apply_alternative(red, comms, alts[win])
+    assert red.comm is comm and red.comm_tail is None and red.algo == 'allreduce'
   torch.save({'params': flat_p.clone(), 'grads': flat_g.clone()}, os.path.join(out_dir, f'r{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()
