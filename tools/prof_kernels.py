@@ -19,7 +19,11 @@ from bench import csrc_sha  # noqa: E402
 from plainlm_amd import _lib, ops  # noqa: E402
 
 BF = torch.bfloat16
-B, T, d, h, V, nh = 32, 1024, 768, 2048, 50280, 12
+# PLM_PROF_CONFIG = 160m (default: the headline step) | 420m (B = 8, T = 2048, d = 1024, h = 2816, 16 heads) | 160m_b8 (the 160M shapes at the reference's
+# document-mask micro-batch of 8); an environment variable, not a flag: nothing but the program may stand behind rocprofv3's "--"
+_CFG = os.environ.get('PLM_PROF_CONFIG', '160m')
+B, T, d, h, V, nh = {'160m': (32, 1024, 768, 2048, 50280, 12), '420m': (8, 2048, 1024, 2816, 50280, 16), '160m_b8': (8, 1024, 768, 2048, 50280, 12)}[_CFG]
+N_BLOCKS = 12  # per grouped dW launch (48 problems = the library's maximum; the 420M step issues two such launches)
 M = B * T
 NT = {'nt qkv fwd': (M, 3 * d, d), 'nt out fwd': (M, d, d), 'nt fc1 fwd': (M, 2 * h, d), 'nt fc2 fwd': (M, d, h), 'nt head fwd': (M, V, d),
       'nt dX qkv': (M, d, 3 * d), 'nt dX fc1': (M, d, 2 * h), 'nt dX fc2': (M, h, d), 'nt dX head': (M, d, 50304)}
@@ -83,7 +87,7 @@ def main():
     del A, Bm, out
   # the dW GEMMs of all twelve blocks as the engine issues them on one GPU: one grouped launch (whole-K tiles + split remainder) + one reduce
   gp = []
-  for _blk in range(12):
+  for _blk in range(N_BLOCKS):
     for name in ('tn dW fc2', 'tn dW fc1', 'tn dW out', 'tn dW qkv'):
       m, n, k = TN[name]
       gp.append((torch.randn(k, m, device='cuda').to(BF), torch.randn(k, n, device='cuda').to(BF), torch.zeros(m, n, device='cuda'), False, None))
@@ -93,22 +97,37 @@ def main():
   torch.cuda.synchronize()
   fl = sum(2.0 * a.shape[1] * b.shape[1] * a.shape[0] for a, b, *_ in gp)
   alg = sum(2.0 * (a.numel() + b.numel()) + 4.0 * o.numel() for a, b, o, *_ in gp)
-  entry('tn dW 12 blocks (grouped x48)', 'gemm_tn', fl, alg, K=M)
-  entry('tn dW 12 blocks (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of='tn dW 12 blocks (grouped x48)')
+  gname = 'tn dW 12 blocks (grouped x48)'
+  entry(gname, 'gemm_tn', fl, alg, K=M)
+  entry('tn dW 12 blocks (grouped reduce)', 'tn_grouped_reduce', 0.0, 0.0, part_of=gname)
   del gp
   # attention: the step's inputs have the statistics of a freshly initialised model (projection outputs ~N(0, 0.4))
   qkv = (0.4 * torch.randn(M, 3 * d, device='cuda')).to(BF)
   dout = (0.01 * torch.randn(M, d, device='cuda')).to(BF)
   from plainlm_amd.transformer import rope_tables
   cos, sin = (t_.cuda() for t_ in rope_tables(64, T))
+  ds = None
+  if _CFG == '160m_b8':  # the reference's document-mask config: random documents, mean length 256 (bench.py --doc-mask)
+    import numpy as np
+    from plainlm_amd.engine import doc_start_from_lengths
+    rng = np.random.default_rng(1234)
+    docs = []
+    for _ in range(B):
+      lens, tot = [], 0
+      while tot < T + 1:
+        n = int(min(rng.geometric(1.0 / 256.0), T + 1 - tot))
+        lens.append(n)
+        tot += n
+      docs.append(lens)
+    ds = doc_start_from_lengths(docs, T).cuda()
   torch.cuda.synchronize()
   for _ in range(2):
-    out, lse = ops.attn_fwd(qkv, B, T, nh)
+    out, lse = ops.attn_fwd(qkv, B, T, nh, ds)
   torch.cuda.synchronize()
   att_fl = 4.0 * B * nh * 64 * T * (T + 1) / 2
   entry('attn fwd', 'attn_fwd', att_fl, 2.0 * (M * 3 * d + M * d), B=B, T=T, nh=nh)
   for _ in range(2):
-    ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh)
+    ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh, ds)
   torch.cuda.synchronize()
   for kname in ('attn_bwd_dq', 'attn_bwd_dkdv', 'attn_bwd_fused', 'attn_bwd_dq_reduce'):
     order.append(dict(name=kname, match=kname, flops=2.0 * att_fl if kname in ('attn_bwd_fused',) else att_fl, algorithmic_bytes=2.0 * (M * 3 * d * 2 + M * d * 2),
