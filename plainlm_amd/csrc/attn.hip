@@ -23,10 +23,6 @@
 
 #include "attn_common.h"
 
-#ifndef PLM_DOC_FWD_NST
-#define PLM_DOC_FWD_NST 2
-#endif
-
 // =============================================================================================
 // RoPE on the q and k column blocks of the w_qkv output, in place (models/embeddings.py:15-30):
 // interleaved pairs (x[2i], x[2i+1]) -> (a cos - b sin, b cos + a sin), fp32 math, bf16 result.
@@ -71,8 +67,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_doc_kernel(const uint16_t* __
                                                           uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh) {
   constexpr int KT = 64;            // kv rows per tile
   constexpr int TILE = KT * 128;    // 8 KiB
-  constexpr int NSTD = PLM_DOC_FWD_NST;  // LDS ring depth (experiment, round 5): tiles are issued NSTD - 1 ahead with counted waits
-  __shared__ __attribute__((aligned(1024))) char smem[NSTD * 2 * TILE];  // [stage][K|V]
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE];  // [stage][K|V]
 
   int tile_, h, b;
   attn_block(T, nh, tile_, h, b);
@@ -123,7 +118,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_doc_kernel(const uint16_t* __
   // one KV tile: S^T = K Q^T, masked online softmax, O^T += V^T P^T
   auto tile_body = [&](int jt, int st) {
     const int kv0 = jt * KT;
-    if (NSTD == 2 && jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
+    if (jt + 1 < jt_hi) stage(st ^ 1, jt + 1);
     const char* sK = smem + st * 2 * TILE;
     const char* sV = sK + TILE;
     if (kv0 <= qw0 + 31) {  // tile not entirely above this wave's diagonal
@@ -182,36 +177,15 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_doc_kernel(const uint16_t* __
         }
       }
     }
-    if (NSTD == 2) {
-      attn_wait_vm<0>();  // next tile landed (this wave's pieces) ...
-      attn_barrier();     // ... everyone's; and every wave is done reading the current stage
-    }
+    attn_wait_vm<0>();  // next tile landed (this wave's pieces) ...
+    attn_barrier();     // ... everyone's; and every wave is done reading the current stage
   };
 
-  if (NSTD == 2) {
-    if (jt_lo < jt_hi) stage(0, jt_lo);
-    attn_wait_vm<0>();
-    attn_barrier();
-    int st = 0;
-    for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st);
-  } else {
-    const int n = jt_hi - jt_lo;
-#pragma unroll
-    for (int i = 0; i < NSTD - 1; ++i)
-      if (i < n) stage(i, jt_lo + i);
-    int slot = 0;
-    for (int i = 0; i < n; ++i) {
-      const int rem = min(NSTD - 2, n - 1 - i);  // tiles issued behind tile i that may stay in flight (4 DMA instructions per wave each)
-      if (NSTD >= 4 && rem >= 2) attn_wait_vm<8>();
-      else if (rem >= 1) attn_wait_vm<4>();
-      else attn_wait_vm<0>();
-      attn_barrier();  // tile i landed for everyone; every wave is done with tile i - 1, whose slot is refilled now
-      if (i + NSTD - 1 < n) stage(slot == 0 ? NSTD - 1 : slot - 1, jt_lo + i + NSTD - 1);
-      tile_body(jt_lo + i, slot);
-      slot = (slot + 1 == NSTD) ? 0 : slot + 1;
-    }
-    attn_barrier();  // the epilogue reuses the stages: every wave must be past its last tile
-  }
+  if (jt_lo < jt_hi) stage(0, jt_lo);
+  attn_wait_vm<0>();
+  attn_barrier();
+  int st = 0;
+  for (int jt = jt_lo; jt < jt_hi; ++jt, st ^= 1) tile_body(jt, st);
 
   float l_lo, l_hi;
   half_pair(lsum, l_lo, l_hi);
