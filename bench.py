@@ -17,6 +17,7 @@ the CPU oracle on the host cores as ``cpu_baseline``.
 """
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -31,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_GBPS = 8000.0     # HBM3E peak (MI355X_MICROARCH.md: ~8 TB/s)
 
 CONFIGS = {
   # BASELINE.json configs[1]/[2]: 12-layer d=768 (160M) seq=1024 bf16, batch 32 per GPU
@@ -40,10 +42,13 @@ CONFIGS = {
 }
 
 
-def flops_per_token(c, hidden):
-  """fwd = L(2d*3d + 2d*d + 2d*2h + 2h*d) + L*2d(T+1) + 2dV ; fwd+bwd = 3x."""
+def flops_per_token(c, hidden, pairs_per_token=None):
+  """fwd = L(2d*3d + 2d*d + 2d*2h + 2h*d) + L*2d(T+1) + 2dV ; fwd+bwd = 3x.  The attention term is
+  4 d x (visible (query, key) pairs per token): (T+1)/2 for the causal mask; with document masks the pairs the mask leaves
+  (``pairs_per_token``, counted from doc_start) - flops the kernels skip are not flops the step did."""
   d, L, T, V = c['d_model'], c['n_layers'], c['seq_len'], c['vocab_size']
-  fwd = L * (2 * d * 3 * d + 2 * d * d + 2 * d * 2 * hidden + 2 * hidden * d) + L * 2 * d * (T + 1) + 2 * d * V
+  pairs = (T + 1) / 2.0 if pairs_per_token is None else pairs_per_token
+  fwd = L * (2 * d * 3 * d + 2 * d * d + 2 * d * 2 * hidden + 2 * hidden * d) + L * 4 * d * pairs + 2 * d * V
   return 3 * fwd
 
 
@@ -74,11 +79,13 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(c, budget_s=28.0):
-  """Oracle (oracle/cpu_ref.py, fp32 eager) fwd+bwd on the host cores: B=1 sequences of seq_len tokens.
-  More threads is not faster for this eager fp32 graph (oversubscription on big hosts), so a few thread counts are
-  tried (one iteration each): ``value`` / ``cores`` are the fastest count's median, ``all_physical_cores`` is the rate
-  with one thread per physical core (SURVEY.md section 8d's definition), reported beside it."""
+def cpu_baseline(c, budget_s=10.0):
+  """Oracle (oracle/cpu_ref.py, fp32 eager) fwd+bwd on the host cores: B=1 sequences of seq_len tokens, a BOUNDED sample (about
+  ``budget_s`` seconds: the GPU part of a default run is well under a second, the baseline must not be the run).
+  More threads is not faster for this eager fp32 graph (oversubscription on big hosts): one untimed warm-up iteration, then one
+  iteration each at 32 threads (the fastest count on every box of this pool so far) and at one thread per physical core (SURVEY.md
+  section 8d's definition), then more iterations at the faster of the two while the budget lasts.  ``value`` / ``cores`` are the faster
+  count's median, ``all_physical_cores`` the rate at one thread per physical core."""
   from oracle import cpu_ref as O
   ocfg = O.OracleConfig(vocab_size=c['vocab_size'], seq_len=c['seq_len'], dim=c['d_model'], n_layers=c['n_layers'],
                         n_heads=c['n_heads'])
@@ -95,29 +102,28 @@ def cpu_baseline(c, budget_s=28.0):
     return time.time() - t0
 
   default_threads = torch.get_num_threads()
-  torch.set_num_threads(min(16, ncpu))
+  n_fast = min(32, ncpu)
+  torch.set_num_threads(n_fast)
   one()  # warm-up (allocations, thread pool)
-  best_n, best_t = None, None
-  for n in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
-    torch.set_num_threads(n)
-    dt = one()
-    if best_t is None or dt < best_t:
-      best_n, best_t = n, dt
-  torch.set_num_threads(nphys)  # SURVEY 8d's definition: one thread per physical core (slower on big hosts: oversubscribed eager ops)
-  t_phys = one()
-  if t_phys < best_t:
-    best_n, best_t = nphys, t_phys
+  best_n, best_t = n_fast, one()
+  t_phys = best_t
+  if nphys != n_fast:
+    torch.set_num_threads(nphys)
+    t_phys = one()
+    if t_phys < best_t:
+      best_n, best_t = nphys, t_phys
   torch.set_num_threads(best_n)
   times = [best_t]
-  while len(times) < 5 and (time.time() - t_all) < budget_s:
+  while len(times) < 5 and (time.time() - t_all) + best_t < budget_s:
     times.append(one())
   torch.set_num_threads(default_threads)
   med = float(np.median(times))
   return {'value': round(c['seq_len'] / med, 1), 'unit': 'tokens/s', 'cores': best_n, 'kind': 'port',
           'all_physical_cores': {'value': round(c['seq_len'] / t_phys, 1), 'cores': nphys},
+          'seconds': round(time.time() - t_all, 1),
           'sample': f'oracle/cpu_ref.py fp32 eager fwd+bwd, batch 1 x {c["seq_len"]} tokens, median of {len(times)} iterations '
-                    f'at the fastest of 16/32/64/{nphys} torch threads (= {best_n}) on a host with {nphys} physical cores / '
-                    f'{ncpu} logical CPUs; all_physical_cores = one iteration with {nphys} threads'}
+                    f'at the faster of {n_fast} / {nphys} torch threads (= {best_n}) on a host with {nphys} physical cores / '
+                    f'{ncpu} logical CPUs, bounded to ~{budget_s:.0f} s; all_physical_cores = one iteration with {nphys} threads'}
 
 
 def csrc_sha():
@@ -245,6 +251,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--config', default='160m', choices=sorted(CONFIGS))
   ap.add_argument('--micro-batch', type=int, default=0)
+  ap.add_argument('--seq-len', type=int, default=0, help='sequence length (default: the config\'s; config/config.yaml:9 ships the 160M model with 2048)')
   ap.add_argument('--no-extras', action='store_true', help='skip the untimed roofline / full-step / cpu legs')
   ap.add_argument('--comm', default=None, choices=[None, 'rccl', 'torch'])
   ap.add_argument('--bucket-mb', type=float, default=64)
@@ -280,6 +287,8 @@ def main():
   c = dict(CONFIGS[a.config])
   if a.micro_batch:
     c['micro_batch'] = a.micro_batch
+  if a.seq_len:
+    c['seq_len'] = a.seq_len
   B, T, V = c['micro_batch'], c['seq_len'], c['vocab_size']
   model = build_model(c, device)
   hidden = model.layers[0].mlp.hidden_dim
@@ -309,6 +318,10 @@ def main():
 
   pool = [(tok[i * B:(i + 1) * B, :T].contiguous().to(device), tok[i * B:(i + 1) * B, 1:].contiguous().to(device),
            doc_starts(B) if a.doc_mask else None) for i in range(n_pool)]
+  pairs_per_token = None  # visible (query, key) pairs per token, mean over the pool's batches: what the masked attention kernels compute
+  if a.doc_mask:
+    pos = torch.arange(T, device=device, dtype=torch.int64)[None, :]
+    pairs_per_token = float(sum((pos - ds.to(torch.int64) + 1).sum().item() for _, _, ds in pool)) / (n_pool * B * T)
 
   def fwd_bwd(i, recast=True):
     ids, tgt, dstart = pool[i % n_pool]
@@ -335,6 +348,12 @@ def main():
     for i in range(warmup):
       loss = fwd_bwd(i)
     torch.cuda.synchronize()
+    # Python's cyclic collector: a full collection walks every object the process holds (import torch alone creates ~10^6) and takes
+    # 60-90 ms of host time - tools/step_times.py shows one such stall every few dozen steps, i.e. +3 ms per step on a 20-step region when it
+    # lands inside.  Collect once here and move the survivors to the permanent generation (gc.freeze: the collector stays ON, later
+    # collections only walk what the steps themselves allocate); plainlm_amd.HipEngine does the same after its first optimizer steps.
+    gc.collect()
+    gc.freeze()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -387,8 +406,11 @@ def main():
     ddp.apply_alternative(st['reducer'], comms, alt)
 
   # ---- the timed region of the contract (for a data-parallel run: on the DEFAULT data plane)
-  elapsed, per_rank, last_loss = timed(a.warmup, a.steps)
-  fpt = flops_per_token(c, hidden)
+  # (data-parallel: the one-off window freeze - a host wait on earlier steps' events + a control-plane all-reduce at the top of step
+  # FREEZE_AFTER + 1 - must land in the warm-up, whatever --warmup says)
+  warm = max(a.warmup, ddp.FREEZE_AFTER + 1) if ddp_on else a.warmup
+  elapsed, per_rank, last_loss = timed(warm, a.steps)
+  fpt = flops_per_token(c, hidden, pairs_per_token)
 
   def line(elapsed, last_loss):
     ms_per_step = 1e3 * elapsed / a.steps
@@ -405,6 +427,9 @@ def main():
       'mfu_bf16': round(value / world * fpt / (PEAK_BF16_TFLOPS * 1e12), 4),
       'flops_per_token': fpt, 'loss': round(last_loss, 4),
     }
+    if pairs_per_token is not None:  # what the same rate would be called if the skipped (masked-out) pairs were counted as work
+      o['mfu_bf16_causal_counted'] = round(value / world * flops_per_token(c, hidden) / (PEAK_BF16_TFLOPS * 1e12), 4)
+      o['attn_pairs_per_token'] = round(pairs_per_token, 1)
     if a.single_device:
       o['data'] = 'synthetic; PLUMBING CHECK ONLY: all ranks share cuda:0, gradients over gloo - not a throughput measurement'
     return o
@@ -441,11 +466,13 @@ def main():
   if ddp_on and not a.no_autotune and os.environ.get('PLM_BENCH_AUTOTUNE', '1') != '0':
     import threading
     deadline = float(os.environ.get('PLM_BENCH_AUTOTUNE_TIMEOUT', '300'))
+    first_out = out  # the first timed region's line: what every failure path below prints (never a half-built later dict)
     def give_up():
-      out['comm']['autotune'] = f'did not finish within {deadline:.0f} s: this line is the timed run on the simplest data plane'
+      first_out['comm']['autotune'] = f'did not finish within {deadline:.0f} s: this line is the timed run on the simplest data plane'
+      first_out['autotune_ok'] = False
       if rank == 0:
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
-      os._exit(0)
+        os.write(json_fd, (json.dumps(first_out) + '\n').encode())
+      os._exit(0 if rank == 0 else 3)  # rank 0 has printed a valid line; the others report the failure through their exit code
     dog = threading.Timer(deadline, give_up)
     dog.daemon = True
     dog.start()
@@ -479,10 +506,11 @@ def main():
     except Exception as e:  # noqa: BLE001 - the first timed region's line must survive whatever the alternatives do
       import traceback
       traceback.print_exc()
-      out['comm']['autotune'] = f'failed on rank {rank} ({type(e).__name__}: {e}): this line is the timed run on the simplest data plane'
+      first_out['comm']['autotune'] = f'failed on rank {rank} ({type(e).__name__}: {e}): this line is the timed run on the simplest data plane'
+      first_out['autotune_ok'] = False
       if rank == 0:
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
-      os._exit(0)  # the other ranks may be inside a collective: no clean shutdown to wait for
+        os.write(json_fd, (json.dumps(first_out) + '\n').encode())
+      os._exit(0 if rank == 0 else 3)  # the other ranks may be inside a collective: no clean shutdown to wait for
     dog.cancel()
   ms_per_step = out['ms_per_step']
   reducer = st['reducer']
@@ -502,11 +530,17 @@ def main():
       acc[2] += 1
     ops.PROFILE = None
     fams = {k: {'TFLOP/s': round(v[0] / v[1] / 1e9, 1), 'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof,
-                'avg_launch_ms': round(v[1] / v[2], 4)} for k, v in fam.items()}
+                'avg_launch_ms': round(v[1] / v[2], 4)} for k, v in fam.items() if not k.startswith('hbm:')}
+    # the HBM-bound kernels (north_star: achieved HBM GB/s on the norm / activation kernels): algorithmic bytes of SURVEY.md section 8d
+    # (12 M d / 16 M d for the norms with their fused adds, 4 M V for cross-entropy in place, 8 B per parameter for the weight casts) over
+    # HIP-event time of the same untimed replay
+    hbm = {k[4:]: {'GB/s': round(v[0] / v[1] / 1e6, 1), 'frac_of_8TBps': round(v[0] / v[1] / 1e6 / PEAK_HBM_GBPS, 4),
+                   'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof, 'avg_launch_ms': round(v[1] / v[2], 4),
+                   'algorithmic_MB_per_launch': round(v[0] / v[2] / 1e6, 1)} for k, v in fam.items() if k.startswith('hbm:')}
     dom = max(fams, key=lambda k: fams[k]['ms_per_step'])
     out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': fams[dom]['TFLOP/s'], 'peak': PEAK_BF16_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': round(fams[dom]['TFLOP/s'] / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-                       'families': fams,
+                       'families': fams, 'hbm': hbm,
                        'families_note': 'gemm_nt = plain NT GEMM launches; gemm_nt_fused = NT launches whose epilogue also does RoPE / SwiGLU / '
                                         'SwiGLU backward (TFLOP/s counts the GEMM flops only, the time includes the fused pass)'}
     out['roofline'].update(pmc_traffic(dom, a.config, B * T, c['n_layers']))

@@ -153,13 +153,13 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (fp32 math, bf16 result).  The training step does not launch it: the
  *               rotation is fused into plm_qkv_rope_bf16's GEMM epilogue; this is that entry point's fallback and the tests' yardstick.
  * Two kernel families behind the same two entry points: doc_start == NULL (plain causal batches) takes the 256-query-tile kernels of
- * csrc/attn_causal.hip, a document mask the 128-row-tile kernels of csrc/attn.hip; lse / delta are only meaningful within one
+ * csrc/attn_causal.hip, a document mask the 128-row-tile kernels of csrc/attn_doc.hip (+ the DOC mode of the causal dK/dV kernel); lse / delta are only meaningful within one
  * forward / backward pair of the same family (pass the same doc_start to both).
  * plm_attn_fwd: qkv with q,k ALREADY rotated -> out bf16[B*T, nh*hd], lse fp32[B, nh, T] (BASE-2 log-sum-exp of the
  *               scaled scores, = LSE / ln 2: the form plm_attn_bwd's exp2 consumes; opaque to the caller otherwise).  No transposed / contiguous copies of q, k, v are made anywhere.
  * plm_attn_bwd: same rotated qkv; dqkv bf16[B*T, 3*nh*hd] = gradient w.r.t. the PRE-rotation q, k (the inverse
  *               rotation is applied in the kernels' epilogues) and v; delta fp32[B,nh,T] scratch (+-rowsum(dO * O), written by the dQ
- *               kernel and read by the dK/dV kernel that follows it; the causal family stores it negated: opaque to the caller).
+ *               kernel and read by the dK/dV kernel that follows it; stored negated: opaque to the caller).
  * qkv, out, dout, dqkv and the RoPE tables must be 16-byte aligned (LDS-DMA sources, whole-row 16-byte epilogue stores); misaligned
  * pointers are refused with PLM_E_INVALID. */
 int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
@@ -184,10 +184,20 @@ int plm_fc1_swiglu_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W, int64
  * one-launch path or returns PLM_E_WORKSPACE without launching anything. */
 int plm_fc2_dx_swiglu_bwd_bf16(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw, const uint16_t* U, uint16_t* DU,
                                uint16_t* scratch, int64_t M, int64_t h, int64_t K, void* stream);
-int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh,
-                 int64_t hd, void* stream);
+/* Document masks (models/transformer.py:52-61 with the masks of data/datasets/data_prep_utils.py:7-23, stacked at engine/engine.py:21-23): a batch's
+ * doc_start[B,T] comes with a PLAN, built once per batch by plm_attn_doc_plan and shared by every layer's forward and backward launches:
+ * doc_end[B,T] (the first query that no longer sees a key: the dK/dV kernel's mask becomes two thresholds per key) and the batch's 128-row
+ * query / key tiles sorted by the number of 64-row tiles they actually walk, heaviest first - the launch order of the kernels; when the
+ * grid of B * ceil(T/128) * nh workgroups is resident at once, the heaviest tiles enter the lists as two 64-row halves (half the chain each).
+ * plan is caller-owned device memory of plm_attn_doc_plan_bytes(B, T) bytes, 16-byte aligned; doc_start must be non-decreasing along T with
+ * doc_start[b][i] <= i.  plm_attn_fwd / plm_attn_bwd: doc_start == NULL -> causal (doc_plan ignored); otherwise doc_plan is required
+ * (PLM_E_INVALID without it). */
+int64_t plm_attn_doc_plan_bytes(int64_t B, int64_t T);
+int plm_attn_doc_plan(const int32_t* doc_start, int32_t* plan, int64_t B, int64_t T, int64_t nh, void* stream);
+int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, const int32_t* doc_plan, uint16_t* out, float* lse, int64_t B, int64_t T,
+                 int64_t nh, int64_t hd, void* stream);
 int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
-                 const float* rope_cos, const float* rope_sin, const int32_t* doc_start,
+                 const float* rope_cos, const float* rope_sin, const int32_t* doc_start, const int32_t* doc_plan,
                  uint16_t* dqkv, float* delta, int64_t B, int64_t T, int64_t nh, int64_t hd, void* stream);
 
 /* ---- fused cross-entropy forward+backward (engine/engine.py:81,111) -----

@@ -17,7 +17,7 @@ _lib = None
 
 # ABI the signatures below were written for (plm_version() of the library must match: a stale .so that still exports every
 # symbol but with other argument lists / struct layouts would corrupt memory instead of raising)
-EXPECTED_ABI = 106
+EXPECTED_ABI = 107
 
 _P = C.c_void_p
 _I64 = C.c_int64
@@ -77,8 +77,10 @@ SIGNATURES = {
   'plm_qkv_rope_bf16': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_fc1_swiglu_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P]),
   'plm_fc2_dx_swiglu_bwd_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _P]),
-  'plm_attn_fwd': (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
-  'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+  'plm_attn_doc_plan_bytes': (_I64, [_I64, _I64]),
+  'plm_attn_doc_plan': (_I, [_P, _P, _I64, _I64, _I64, _P]),
+  'plm_attn_fwd': (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+  'plm_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_ce_fwd_bwd': (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P]),
   'plm_mean_f32': (_I, [_P, _P, _I64, _P]),
   'plm_scale_bf16': (_I, [_P, _I64, _P, _P]),

@@ -46,7 +46,9 @@ constexpr int ATTN_DMA_PER_STAGE = 4;
 constexpr int ATTN_DMA_STATS = 2;  // dK/dV kernel, wave 0: the LSE and delta rows of the query tile
 static_assert(ATTN_DMA_PER_STAGE == 2 * 2, "stage() = two TileDma::issue calls of two instructions each");
 
-#define ATTN_DEFER_LOG2 8.0f  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
+#define ATTN_DEFER_LOG2 8.0f
+#define PLM_ATTN_TRACE_SETTER plm_dbg_attn_trace_causal
+ATTN_TRACE_DECL()  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
 
 enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };  // a 32-row block on a key tile: above its diagonal / no mask needed / masked
 
@@ -425,24 +427,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
   const RowStage rs{smem + (n % NST) * 2 * TILE + wave * 4096, lane};  // a slot nobody reads any more (see the forward kernel)
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const int trow = min(r0[qb] + l31, T - 1) * 32;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
-        const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
-        const float a0_ = dq[qb][db][4 * g + 0] * scale, b0 = dq[qb][db][4 * g + 1] * scale, a1_ = dq[qb][db][4 * g + 2] * scale,
-                    b1 = dq[qb][db][4 * g + 3] * scale;
-        bf16x4_t ov;  // inverse rotation: gradient w.r.t. the PRE-rotation q
-        ov[0] = f2bf(a0_ * c0 + b0 * s0);
-        ov[1] = f2bf(b0 * c0 - a0_ * s0);
-        ov[2] = f2bf(a1_ * c1 + b1 * s1);
-        ov[3] = f2bf(b1 * c1 - a1_ * s1);
+        bf16x4_t ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(dq[qb][db][4 * g + e] * scale);
         rs.put(l31, hi, db * 4 + g, ov);
       }
-    rs.flush(dqkv + (int64_t)b * T * ld, ld, r0[qb], T, h * HD);
+    rs.flush_rot(dqkv + (int64_t)b * T * ld, ld, r0[qb], T, h * HD, rcos, rsin);  // inverse rotation: gradient w.r.t. the PRE-rotation q
   }
 }
 
@@ -450,24 +444,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
 // backward dK / dV: 4 waves x 32 key rows (128-key tiles, K / V of a wave's rows in registers), Q | dO | statistics tiles of 64
 // queries through an NST-deep ring filled NST - 1 tiles ahead; every fragment of a 32-query block is requested before the block's first MFMA.
 // =============================================================================================
-template <int NST>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                                const float* __restrict__ lse, const float* __restrict__ ndelta,
-                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                                uint16_t* __restrict__ dqkv, int T, int nh) {
+// DOC (document masks, doc_start[B,T]): key j is seen by the queries j .. doc_end[j] - 1 (doc_start is non-decreasing, so the set is contiguous;
+// doc_end[] comes from the plan kernel of attn_doc.hip) - in this kernel's S[q][kv] layout a lane owns a KEY, so the mask stays what it is in the
+// causal case: two integer thresholds per lane (c_lo from the key's own index, c_end from its doc_end instead of T).  The workgroup takes its
+// item (batch, first key, one past the last query tile, kind) from the plan's sorted list instead of the tile-major causal order.
+// (Key tiles are never split into 64-key items the way the forward / dQ kernels split their heavy query tiles: with two workgroups per CU this
+// kernel's grid is not resident at once at the reference's micro-batch, its launch lasts two rounds of fixed costs rather than one longest
+// chain, and halving the chains changed nothing - tools/attn_trace.py, profiles/r06_attn_trace_*.)
+template <int NST, bool DOC>
+__device__ __forceinline__ void attn_bwd_dkdv_body(char* smem, const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                   const float* __restrict__ lse, const float* __restrict__ ndelta,
+                                                   const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                   const int32_t* __restrict__ doc_end, uint16_t* __restrict__ dqkv, int T, int nh, int b, int h,
+                                                   int kv0, int jq_plan, unsigned long long* trace_t = nullptr) {
   constexpr int QT = 64;
   constexpr int TILE = QT * 128;          // 8 KiB
   constexpr int STAGE = 2 * TILE + 512;   // Q | dO | statistics (lse[64], delta[64])
-  constexpr int KB = 128;
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
-
-  int kt, h, b;  // key tile 0 meets every query tile: heaviest first
-  attn_block2<KB>(T, nh, kt, h, b);
+  constexpr int NQB = 2;                  // 32-query blocks of a query tile
+  constexpr bool LEAN = false;            // (an experiment kept for the record: statistics folded into the score accumulators, transposed fragments
+                                          //  requested behind the first MFMAs - still 74 spills at the 168 registers of three workgroups per CU)
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int kv0 = kt * KB, kvw0 = kv0 + wave * 32;
+  constexpr int qoff = 0;
+  const int kvw0 = kv0 + 32 * wave;
   const int kvrow = kvw0 + l31;
   const bool kvalid = kvrow < T;
   const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
@@ -476,22 +477,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
   const float* drow = ndelta + ((int64_t)b * nh + h) * T;
   const float scale = 0.125f, c2 = scale * LOG2E;
 
-  bf16x8_t kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
-    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
-    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
-  }
   const int nqt = (T + QT - 1) / QT;
   const int jq_lo = kv0 / QT;
-  const int jq_hi = nqt;
+  const int jq_hi = DOC ? jq_plan : nqt;
   const int n = jq_hi - jq_lo;
-  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
-               "v"(vf[3]));  // every ordinary load is consumed before the first DMA is in flight
-
-  f32x16_t dk[2], dv[2];
-  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
 
   TileDma dma, dmad;
   dma.init(wave, lane, ld);
@@ -512,6 +501,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
       dma16_asm(drow + q, dst + 2 * TILE + 256);
     }
   };
+  // the first Q | dO tiles are on their way before the wave's K / V rows are asked for (the two latencies overlap; the ordinary loads are
+  // younger than the DMA, so waiting for them covers it)
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < n) stage(i, jq_lo + i);
+
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
+    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
+    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
+  }
+  int de = T;  // first query that does not see this lane's key
+  if (DOC) de = doc_end[(int64_t)b * T + min(kvrow, T - 1)];
+  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
+               "v"(vf[3]), "v"(de));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed: nothing but LDS-DMA is counted from here on
+  const int de_lo = DOC ? __builtin_amdgcn_readlane(de, 0) : T, de_hi = DOC ? __builtin_amdgcn_readlane(de, 31) : T;  // the wave's first / last key
+
+  f32x16_t dk[2], dv[2];
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
 
   auto compute = [&](int qt0, const char* sQ, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
@@ -519,39 +530,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
     const float* sL = reinterpret_cast<const float*>(sQ + 2 * TILE);
     const float* sD = sL + 64;
     // query r = 4g + e of this lane is tile row qb*32 + 8g + e + 4*hi: visible iff  c_lo <= qb*32 + 8g + e < c_end
-    const int c_lo = kvrow - qt0 - 4 * hi, c_end = T - qt0 - 4 * hi;
+    const int c_lo = kvrow - qt0 - qoff - 4 * hi, c_end = de - qt0 - qoff - 4 * hi;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
       __builtin_amdgcn_sched_barrier(0);  // one query block's fragments at a time
-      if (MASK && qt0 + qb * 32 + 31 < kvw0) continue;  // every query of the block precedes this wave's first key: P = 0 (wave-uniform)
+      if (MASK && qt0 + qoff + qb * 32 + 31 < kvw0) continue;  // every query of the block precedes this wave's first key: P = 0 (wave-uniform)
+      if (DOC && MASK && qt0 + qoff + qb * 32 >= de_hi) continue;  // ... or lies behind the document of its last key
       bf16x8_t qfr[4], dofr[4], dotr[2][2], qtr[2][2];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        qfr[ks] = frag_rows(sQ, qb * 32 + l31, ks, hi);
-        dofr[ks] = frag_rows(sDO, qb * 32 + l31, ks, hi);
+        qfr[ks] = frag_rows(sQ, qoff + qb * 32 + l31, ks, hi);
+        dofr[ks] = frag_rows(sDO, qoff + qb * 32 + l31, ks, hi);
       }
       f32x4_t L4[4];
       f32x16_t s, dp;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int ql0 = qb * 32 + 8 * g + 4 * hi;
+        const int ql0 = qoff + qb * 32 + 8 * g + 4 * hi;
         L4[g] = *reinterpret_cast<const f32x4_t*>(sL + ql0);  // base-2 LSE
         const f32x4_t nd = *reinterpret_cast<const f32x4_t*>(sD + ql0);  // -delta: the dP accumulators start from it (dP' = dP - delta)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];
+        // LEAN: the score accumulators start from -LSE / c2 in the same way (p = exp2(c2 s') with s' = s - LSE / c2): the statistics die here
+        if (LEAN)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[4 * g + e] = L4[g][e] * (-1.f / c2);
       }
+      auto read_tr = [&]() {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dotr[db][s2] = frag_cols(sDO, db, qb * 32 + s2 * 16 + 4 * hi, lane);
-          qtr[db][s2] = frag_cols(sQ, db, qb * 32 + s2 * 16 + 4 * hi, lane);
-        }
-      zero16(s);
+          for (int db = 0; db < 2; ++db) {
+            dotr[db][s2] = frag_cols(sDO, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane);
+            qtr[db][s2] = frag_cols(sQ, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane);
+          }
+      };
+      if (!LEAN) {
+        read_tr();  // every fragment of the block is requested before its first MFMA
+        zero16(s);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(qfr[ks], kf[ks], s);       // S[q][kv]
         dp = mfma32(dofr[ks], vf[ks], dp);    // dP'[q][kv]
+      }
+      if (LEAN) {
+        __builtin_amdgcn_sched_barrier(0);  // the row fragments are dead: the transposed ones take their registers, their latency hides behind the arithmetic below
+        read_tr();
       }
       bf16x8_t pf[2], dsf[2];
 #pragma unroll
@@ -559,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          float p = fast_exp2(__builtin_fmaf(s[r], c2, -L4[g][e]));
+          float p = LEAN ? fast_exp2(s[r] * c2) : fast_exp2(__builtin_fmaf(s[r], c2, -L4[g][e]));
           if (MASK) {
             const int c = qb * 32 + 8 * g + e;
             p = ((c >= c_lo) && (c < c_end)) ? p : 0.f;
@@ -580,13 +605,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
 
   // per wave: tiles entirely above its first key (idle), the tiles its diagonal crosses (masked), the tiles below its last key (no mask),
   // a partial last tile when T % 64 != 0 (masked)
+  // (DOC: ... the tiles behind the document of its first key (masked again), the tiles behind the document of its last key (idle))
   const bool wave_rows = kvw0 < T;
   const int jq_act = wave_rows ? min(jq_hi, max(jq_lo, kvw0 / QT)) : jq_hi;
   const int jq_m = min(jq_hi, max(jq_act, (kvw0 + 31 + QT - 1) / QT));
-  const int jq_u = min(jq_hi, max(jq_m, T / QT));
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)
-    if (i < n) stage(i, jq_lo + i);
+  const int jq_u = min(jq_hi, max(jq_m, de_lo / QT));
+  const int jq_e = min(jq_hi, max(jq_u, (de_hi + QT - 1) / QT));
+#ifdef PLM_ATTN_TRACE
+  if (trace_t) trace_t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
   int i = 0, slot = 0;
   auto run = [&](int jq_end, auto mask_tag, bool active) {
     for (; jq_lo + i < jq_end; ++i) {
@@ -612,10 +639,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
   run(jq_act, std::true_type{}, false);
   run(jq_m, std::true_type{}, true);
   run(jq_u, std::false_type{}, true);
-  run(jq_hi, std::true_type{}, true);
+  run(jq_e, std::true_type{}, true);
+  if (DOC) run(jq_hi, std::true_type{}, false);
+#ifdef PLM_ATTN_TRACE
+  if (trace_t) trace_t[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const RowStage rs{smem + (n % NST) * STAGE + wave * 4096, lane};  // a slot nobody reads any more (see the forward kernel)
-  const int trow = min(kvrow, T - 1) * 32;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -630,18 +660,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int d0 = db * 32 + 8 * g + 4 * hi;
-      const float c0 = rcos[trow + d0 / 2], c1 = rcos[trow + d0 / 2 + 1];
-      const float s0 = rsin[trow + d0 / 2], s1 = rsin[trow + d0 / 2 + 1];
-      const float a0 = dk[db][4 * g + 0] * scale, b0 = dk[db][4 * g + 1] * scale, a1 = dk[db][4 * g + 2] * scale, b1 = dk[db][4 * g + 3] * scale;
-      bf16x4_t ok;  // inverse rotation of the two (even, odd) pairs of dK: gradient w.r.t. the PRE-rotation k
-      ok[0] = f2bf(a0 * c0 + b0 * s0);
-      ok[1] = f2bf(b0 * c0 - a0 * s0);
-      ok[2] = f2bf(a1 * c1 + b1 * s1);
-      ok[3] = f2bf(b1 * c1 - a1 * s1);
+      bf16x4_t ok;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ok[e] = f2bf(dk[db][4 * g + e] * scale);
       rs.put(l31, hi, db * 4 + g, ok);
     }
-  rs.flush(dqkv + (int64_t)b * T * ld, ld, kvw0, T, dm + h * HD);
+  rs.flush_rot(dqkv + (int64_t)b * T * ld, ld, kvw0, T, dm + h * HD, rcos, rsin);  // inverse rotation: gradient w.r.t. the PRE-rotation k
+}
+
+
+template <int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                                      const float* __restrict__ lse, const float* __restrict__ ndelta,
+                                                                      const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                      uint16_t* __restrict__ dqkv, int T, int nh) {
+  __shared__ __attribute__((aligned(1024))) char smem[NST * (2 * 8192 + 512)];
+  int kt, h, b;  // key tile 0 meets every query tile: heaviest first
+  attn_block2<128>(T, nh, kt, h, b);
+  attn_bwd_dkdv_body<NST, false>(smem, qkv, dout, lse, ndelta, rcos, rsin, nullptr, dqkv, T, nh, b, h, kt * 128, 0);
+}
+
+template <int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_doc_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ ndelta,
+                                                                   const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                   const int32_t* __restrict__ header, const int32_t* __restrict__ doc_end,
+                                                                   const int4* __restrict__ items, uint16_t* __restrict__ dqkv, int T, int nh) {
+  __shared__ __attribute__((aligned(1024))) char smem[NST * (2 * 8192 + 512)];
+  ATTN_TRACE_T(tr0);
+  const int idx = blockIdx.x / nh, h = blockIdx.x - idx * nh;
+  if (idx >= __builtin_amdgcn_readfirstlane(header[0])) return;
+  const int4 it = items[idx];
+  const int b = __builtin_amdgcn_readfirstlane(it.x), kv0 = __builtin_amdgcn_readfirstlane(it.y), jq_hi = __builtin_amdgcn_readfirstlane(it.z);
+  const int kc = __builtin_amdgcn_readfirstlane(it.w);
+  (void)kc;
+#ifdef PLM_ATTN_TRACE
+  unsigned long long tt[2] = {0, 0};
+#else
+  unsigned long long* tt = nullptr;
+#endif
+  attn_bwd_dkdv_body<NST, true>(smem, qkv, dout, lse, ndelta, rcos, rsin, doc_end, dqkv, T, nh, b, h, kv0, jq_hi, tt);
+  ATTN_TRACE_END(2, idx, kc, tr0, tt[0], tt[1]);
 }
 
 // =============================================================================================
@@ -656,5 +715,13 @@ void plm_attn_bwd_causal(const uint16_t* qkv, const uint16_t* out, const uint16_
   const dim3 block(256);
   // dQ first: it computes delta[b,h,q] for its queries and publishes -delta for the dK/dV kernel (which reads it straight into its dP accumulators)
   hipLaunchKernelGGL((attn_bwd_dq_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 256) * nh * B)), block, 0, s, qkv, out, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh, -1.f);
-  hipLaunchKernelGGL((attn_bwd_dkdv_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), block, 0, s, qkv, dout, lse, delta, rc, rs, dqkv, (int)T, (int)nh);
+  hipLaunchKernelGGL((attn_bwd_dkdv_causal_kernel<3>), dim3((unsigned)(plm_cdiv(T, 128) * nh * B)), block, 0, s, qkv, dout, lse, delta, rc, rs, dqkv,
+                     (int)T, (int)nh);
+}
+// dK / dV of a document-masked batch (the dQ kernel of attn_doc.hip runs first and publishes -delta)
+void plm_attn_bwd_dkdv_doc(const uint16_t* qkv, const uint16_t* dout, const float* lse, const float* ndelta, const float* rc, const float* rs,
+                           const int32_t* header, const int32_t* doc_end, const int4* items_k, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh,
+                           hipStream_t s) {
+  hipLaunchKernelGGL((attn_bwd_dkdv_doc_kernel<3>), dim3((unsigned)(doc_plan_cap(B, T) * nh)), dim3(256), 0, s, qkv, dout, lse, ndelta, rc, rs,
+                     header, doc_end, items_k, dqkv, (int)T, (int)nh);
 }

@@ -1,4 +1,5 @@
-// Device helpers shared by the attention kernels (attn.hip, attn_pipe.hip): LDS tile image, fragment reads, LDS-DMA of tiles.
+// Device helpers shared by the attention kernels (attn.hip, attn_causal.hip, attn_doc.hip): LDS tile image, fragment reads, LDS-DMA of tiles,
+// and the layout of the document-mask plan.
 #pragma once
 #include "plm_device.h"
 
@@ -102,5 +103,84 @@ struct RowStage {
       if (row0 + row < row_end) st_bf16x8(dst + (int64_t)(row0 + row) * ld + col0 + c16 * 8, v);
     }
   }
+  // The same with the INVERSE RoPE rotation applied to the staged bf16 values on their way out (dQ, dK: the gradient w.r.t. the
+  // un-rotated projection; models/embeddings.py:15-30 differentiated).  After the transposition a lane holds 8 consecutive head dims = 4
+  // pairs of one row, so its cos / sin values are ONE 16-byte load per table, 8 lanes cover a table row: 8 fully used lines per
+  // instruction.  (Rotating the fp32 accumulators in their MFMA layout instead took 32 four-byte loads per lane that touched 32 lines
+  // each: ~3 us of every backward workgroup's life, tools/attn_trace.py.)  The value is rounded to bf16 before the rotation and again after
+  // it - the reference's own order (SDPA's backward returns bf16, the rotation's backward runs in fp32 and casts back).
+  __device__ __forceinline__ void flush_rot(uint16_t* dst, int64_t ld, int row0, int row_end, int col0, const float* __restrict__ rcos,
+                                            const float* __restrict__ rsin) const {
+    f32x4_t cs[4], sn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // issued before the LDS round trip is waited for
+      const int trow = min(row0 + 8 * i + (lane >> 3), row_end - 1);
+      cs[i] = *reinterpret_cast<const f32x4_t*>(rcos + trow * (HD / 2) + (lane & 7) * 4);
+      sn[i] = *reinterpret_cast<const f32x4_t*>(rsin + trow * (HD / 2) + (lane & 7) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3), c16 = lane & 7;
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(base + row * 128 + ((c16 ^ (row & 7)) << 4));
+      if (row0 + row < row_end) st_bf16x8(dst + (int64_t)(row0 + row) * ld + col0 + c16 * 8, rope8(v, cs[i], sn[i], -1.f));
+    }
+  }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Document-mask plan (plm_attn_doc_plan, attn_doc.hip), int32 units, for a batch of doc_start[B][T] and nh heads:
+//   [0, 8)                        header {number of query items, number of key items, 0 ...}
+//   [8, 8 + B*T)                  doc_end[b][j]: first query that does NOT see key j (queries j .. doc_end - 1 do; doc_start is non-decreasing)
+//   [pq, pq + 4 cap)              query items {b, first row, first key tile (64 keys) of the item's first row, kind << 30 | cost}
+//   [pq + 4 cap, pq + 8 cap)      key items   {b, first key, one past the last query tile (64 rows) that sees a key of the item, kind << 30 | cost}
+// with pq = 8 + B*T rounded up to a multiple of 4, n = B * ceil(T / 128) tiles and cap = n + n / 4 items per list.
+// An item is a 128-row tile (kind 0: four waves x 32 rows) or - when the whole grid is resident at once and the launch therefore lasts as long as
+// its longest chain of tile steps - one 64-row half of a HEAVY tile (kind 1: 2 row blocks x 2 halves of every streamed tile, partial results
+// combined in LDS; half the chain).  Both lists are sorted by their expected duration, longest first: the hardware hands workgroups out in
+// blockIdx order, so the grid is a longest-processing-time-first schedule of the ACTUAL work - with document masks the work of a tile no
+// longer follows from its index.  The kernels are launched with cap * nh workgroups; those beyond the header's count leave at once.
+// ---------------------------------------------------------------------------------------------
+struct DocPlan {
+  const int32_t* header;
+  const int32_t* doc_end;
+  const int4* items_q;
+  const int4* items_k;
+};
+constexpr int DOC_KIND_SHIFT = 30;
+__host__ __device__ __forceinline__ int64_t doc_plan_tiles(int64_t B, int64_t T) { return B * ((T + 127) / 128); }
+__host__ __device__ __forceinline__ int64_t doc_plan_cap(int64_t B, int64_t T) { return doc_plan_tiles(B, T) + doc_plan_tiles(B, T) / 4; }
+__host__ __device__ __forceinline__ int64_t doc_plan_pq(int64_t B, int64_t T) { return (8 + B * T + 3) & ~(int64_t)3; }
+__host__ __device__ __forceinline__ int64_t doc_plan_ints(int64_t B, int64_t T) { return doc_plan_pq(B, T) + 8 * doc_plan_cap(B, T); }
+__host__ __device__ __forceinline__ DocPlan doc_plan_view(const int32_t* plan, int64_t B, int64_t T) {
+  DocPlan p;
+  p.header = plan;
+  p.doc_end = plan + 8;
+  p.items_q = reinterpret_cast<const int4*>(plan + doc_plan_pq(B, T));
+  p.items_k = p.items_q + doc_plan_cap(B, T);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// -DPLM_ATTN_TRACE (tools/attn_trace.py builds such a copy of the library; never the shipped one): every workgroup of a document-mask kernel
+// leaves {start, loop start, loop end, end} on the 100 MHz wall clock, its CU (HW_ID / XCC_ID), rank and cost in a host-provided buffer.
+// ---------------------------------------------------------------------------------------------
+#ifdef PLM_ATTN_TRACE
+#define ATTN_TRACE_DECL()                                                                    \
+  static __device__ unsigned long long* g_attn_trace = nullptr;                               \
+  extern "C" int PLM_ATTN_TRACE_SETTER(unsigned long long* buf) {                             \
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf));               \
+  }
+#define ATTN_TRACE_T(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define ATTN_TRACE_END(kid, rank_, cost_, t0, t1, t2)                                                                              \
+  if (threadIdx.x == 0 && g_attn_trace) {                                                                                          \
+    unsigned long long* r_ = g_attn_trace + ((size_t)(kid) * 65536 + blockIdx.x) * 8;                                             \
+    r_[0] = t0; r_[1] = t1; r_[2] = t2; r_[3] = __builtin_amdgcn_s_memrealtime();                                                 \
+    r_[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); r_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                         \
+    r_[6] = (unsigned long long)(rank_); r_[7] = (unsigned long long)(cost_);                                                      \
+  }
+#else
+#define ATTN_TRACE_DECL()
+#define ATTN_TRACE_T(var)
+#define ATTN_TRACE_END(kid, rank_, cost_, t0, t1, t2)
+#endif

@@ -38,6 +38,7 @@ struct PlmEnv {
   bool tn_no_big;             // PLM_TN_NO_BIG: no persistent 256x256 TN kernel
   bool nt_no_hybrid;          // PLM_NT_NO_HYBRID: no whole-K + stream-K NT schedule
   long long nt_hybrid_min_k;  // PLM_NT_HYBRID_MIN_K: lowers the hybrid schedule's thresholds (-1: defaults)
+  int attn_doc_split_min;     // PLM_ATTN_DOC_SPLIT_MIN: tile steps from which a heavy document-mask QUERY tile is split into two 64-row items (default 8; 0: never)
 };
 const PlmEnv& plm_env();
 

@@ -318,15 +318,30 @@ class SwiGLUFn(torch.autograd.Function):
     return ops.swiglu_bwd(dout.contiguous(), u)
 
 
+class DocMask:
+  """A document mask as the kernels take it: ``doc_start`` int32 [B,T] (query i sees key j iff doc_start[i] <= j <= i) and its
+  plan (ops.attn_doc_plan: doc_end[B,T] + the cost-sorted tile lists), built once per batch and shared by all layers."""
+  __slots__ = ('doc_start', 'plan', 'n_heads')
+
+  def __init__(self, doc_start, n_heads, plan=None):
+    self.doc_start = doc_start
+    self.n_heads = n_heads
+    self.plan = ops.attn_doc_plan(doc_start, n_heads) if plan is None else plan
+
+
 class AttnFn(torch.autograd.Function):
-  """RoPE + causal/doc-masked SDPA on the raw w_qkv output (transformer.py:43-65)."""
+  """RoPE + causal/doc-masked SDPA on the raw w_qkv output (transformer.py:43-65).  ``doc``: None (causal), a DocMask, or a bare
+  int32 doc_start [B,T] (its plan is then built per call)."""
 
   @staticmethod
-  def forward(ctx, qkv, cos, sin, doc_start, B, T, nh):
+  def forward(ctx, qkv, cos, sin, doc, B, T, nh):
     # qkv arrives with q, k already rotated (QKVRopeFn); attn_bwd returns the gradient w.r.t. the UN-rotated projection.
-    out, lse = ops.attn_fwd(qkv, B, T, nh, doc_start)
+    if doc is not None and (not isinstance(doc, DocMask) or doc.n_heads != nh):
+      doc = DocMask(doc.doc_start if isinstance(doc, DocMask) else doc, nh)
+    ds, plan = (doc.doc_start, doc.plan) if doc is not None else (None, None)
+    out, lse = ops.attn_fwd(qkv, B, T, nh, ds, plan)
     ctx.save_for_backward(qkv, out, lse, cos, sin)
-    ctx.doc_start = doc_start
+    ctx.doc = doc
     ctx.dims = (B, T, nh)
     return out
 
@@ -334,7 +349,8 @@ class AttnFn(torch.autograd.Function):
   def backward(ctx, dout):
     qkv, out, lse, cos, sin = ctx.saved_tensors
     B, T, nh = ctx.dims
-    dqkv = ops.attn_bwd(qkv, out, dout.contiguous(), lse, cos, sin, B, T, nh, ctx.doc_start)
+    ds, plan = (ctx.doc.doc_start, ctx.doc.plan) if ctx.doc is not None else (None, None)
+    dqkv = ops.attn_bwd(qkv, out, dout.contiguous(), lse, cos, sin, B, T, nh, ds, plan)
     return dqkv, None, None, None, None, None, None
 
 

@@ -19,8 +19,9 @@ def _stream():
   return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, every MFMA
-# kernel launch is bracketed by HIP events on the launch stream and (family, flops, start, end) appended.
+# Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, every MFMA kernel launch - and every launch of the
+# HBM-bound kernels, whose family names start with 'hbm:' and whose work figure is ALGORITHMIC BYTES instead of
+# flops - is bracketed by HIP events on the launch stream and (family, work, start, end) appended.
 PROFILE = None
 # Called with (family, flops) right before every MFMA kernel launch when set (ddp.GradReducer: it keeps an estimate of the GPU time
 # enqueued so far and reserves CUs for RCCL only while a gradient bucket's collective is expected to be running).
@@ -105,7 +106,8 @@ def cast_bf16_t_multi(items):
     if out_t.dtype != BF16 or out_t.dim() != 2 or out_t.shape[0] != Cc or out_t.shape[1] < R or out_t.stride(1) != 1 or not out_t.is_cuda:
       raise ValueError('cast_bf16_t_multi.out_t: need bf16 [C, >=R] on the GPU')
     arr[i] = _lib.CastItem(src.data_ptr(), out.data_ptr(), out_t.data_ptr(), R, Cc, out_t.stride(0))
-  _lib.check(_lib.load().plm_cast_f32_bf16_t_multi(arr, len(items), _stream()), 'plm_cast_f32_bf16_t_multi')
+  with _Timed('hbm:cast_bf16_t_multi', 8.0 * sum(src.numel() for src, _, _ in items)):  # one fp32 read, the bf16 copy and its transpose written
+    _lib.check(_lib.load().plm_cast_f32_bf16_t_multi(arr, len(items), _stream()), 'plm_cast_f32_bf16_t_multi')
 
 
 # ---- embedding ----------------------------------------------------------------
@@ -114,7 +116,8 @@ def embed_fwd(ids, W):
   _need(W, F32, 'embed_fwd.W', 2)
   M = ids.numel()
   out = torch.empty((M, W.shape[1]), dtype=F32, device=W.device)
-  _lib.check(_lib.load().plm_embed_fwd(_p(ids), _p(W), _p(out), M, W.shape[1], W.shape[0], _stream()), 'plm_embed_fwd')
+  with _Timed('hbm:embed_fwd', 8.0 * M * W.shape[1] + 8.0 * M):
+    _lib.check(_lib.load().plm_embed_fwd(_p(ids), _p(W), _p(out), M, W.shape[1], W.shape[0], _stream()), 'plm_embed_fwd')
   return out
 
 
@@ -146,8 +149,9 @@ def embed_bwd_sorted(ids, dout, dW, accumulate):
   ws = _embed_ws.get(dout.device)
   if ws is None or ws.numel() < nbytes:
     ws = _embed_ws[dout.device] = torch.empty(nbytes, dtype=torch.uint8, device=dout.device)
-  _lib.check(lib.plm_embed_bwd_sorted(_p(ids), _p(dout), _p(dW), ids.numel(), dW.shape[1], dW.shape[0], int(bool(accumulate)),
-                                      _p(ws), nbytes, _stream()), 'plm_embed_bwd_sorted')
+  with _Timed('hbm:embed_bwd', 4.0 * dout.numel() + (8.0 if accumulate else 4.0) * dW.numel() + 8.0 * ids.numel()):
+    _lib.check(lib.plm_embed_bwd_sorted(_p(ids), _p(dout), _p(dW), ids.numel(), dW.shape[1], dW.shape[0], int(bool(accumulate)),
+                                        _p(ws), nbytes, _stream()), 'plm_embed_bwd_sorted')
   return True
 
 
@@ -162,8 +166,9 @@ def rmsnorm_fwd(x, w, eps, branch=None, write_xout=False):
   xout = torch.empty_like(x) if (write_xout or branch is not None) else None
   y = torch.empty((M, d), dtype=BF16, device=x.device)
   rstd = torch.empty((M,), dtype=F32, device=x.device)
-  _lib.check(_lib.load().plm_rmsnorm_fwd(_p(x), _p(branch), _p(xout), _p(w), _p(y), _p(rstd), M, d, float(eps), _stream()),
-             'plm_rmsnorm_fwd')
+  with _Timed('hbm:rmsnorm_fwd', (6.0 + (2.0 if branch is not None else 0.0) + (4.0 if xout is not None else 0.0)) * M * d):
+    _lib.check(_lib.load().plm_rmsnorm_fwd(_p(x), _p(branch), _p(xout), _p(w), _p(y), _p(rstd), M, d, float(eps), _stream()),
+               'plm_rmsnorm_fwd')
   return xout, y, rstd
 
 
@@ -181,8 +186,9 @@ def rmsnorm_bwd(dy, x, w, rstd, gin=None, want_bf16=False, dw_out=None, dw_accum
   dxb = torch.empty((M, d), dtype=BF16, device=x.device) if want_bf16 else None
   nblk = lib.plm_rmsnorm_bwd_blocks(M)
   part = torch.empty((nblk, d), dtype=F32, device=x.device)
-  _lib.check(lib.plm_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(gin), _p(dx), _p(dxb), _p(part), M, d, _stream()),
-             'plm_rmsnorm_bwd')
+  with _Timed('hbm:rmsnorm_bwd', (10.0 + (4.0 if gin is not None else 0.0) + (2.0 if want_bf16 else 0.0)) * M * d):
+    _lib.check(lib.plm_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(gin), _p(dx), _p(dxb), _p(part), M, d, _stream()),
+               'plm_rmsnorm_bwd')
   if defer_dw:
     return dx, dxb, part
   if dw_out is None:
@@ -438,28 +444,60 @@ def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
   return out
 
 
-def attn_fwd(qkv_rot, B, T, nh, doc_start=None):
-  """qkv_rot: projection output with q, k already rotated (rope_qk_)."""
+def attn_doc_plan(doc_start, nh):
+  """Plan of a document-masked batch for attention with nh heads (include/plainlm_hip.h: doc_end[B,T] + the sorted item lists): built ONCE
+  per batch, shared by every layer's forward / backward launches."""
+  _need(doc_start, torch.int32, 'attn_doc_plan.doc_start', 2)
+  B, T = doc_start.shape
+  lib = _lib.load()
+  plan = torch.empty((lib.plm_attn_doc_plan_bytes(B, T) // 4,), dtype=torch.int32, device=doc_start.device)
+  _lib.check(lib.plm_attn_doc_plan(_p(doc_start), _p(plan), B, T, nh, _stream()), 'plm_attn_doc_plan')
+  return plan
+
+
+def attn_flops(B, T, nh, hd, doc_start=None):
+  """Algorithmic flops of the forward pass: 2 matmuls x 2 flop x hd per visible (query, key) pair - causal T(T+1)/2 pairs per head and
+  sequence, with a document mask the pairs doc_start[i] <= j <= i (one small device reduction, cached on the tensor)."""
+  if doc_start is None:
+    return 4.0 * B * nh * hd * T * (T + 1) / 2
+  pairs = getattr(doc_start, '_plm_pairs', None)
+  if pairs is None:
+    pos = torch.arange(T, device=doc_start.device, dtype=torch.int64)[None, :]
+    pairs = float((pos - doc_start.to(torch.int64) + 1).sum().item())
+    try:
+      doc_start._plm_pairs = pairs
+    except AttributeError:
+      pass
+  return 4.0 * nh * hd * pairs
+
+
+def attn_fwd(qkv_rot, B, T, nh, doc_start=None, plan=None):
+  """qkv_rot: projection output with q, k already rotated (rope_qk_).  doc_start: int32 [B,T] document mask; plan: attn_doc_plan(doc_start)
+  (built here when absent - pass it when the same batch goes through several layers)."""
   _need(qkv_rot, BF16, 'attn_fwd.qkv', 2)
   hd = qkv_rot.shape[1] // (3 * nh)
   if doc_start is not None:
     _need(doc_start, torch.int32, 'attn_fwd.doc_start', 2)
+    if plan is None:
+      plan = attn_doc_plan(doc_start, nh)
   out = torch.empty((B * T, nh * hd), dtype=BF16, device=qkv_rot.device)
   lse = torch.empty((B, nh, T), dtype=F32, device=qkv_rot.device)
-  _hook('attn_fwd', 4.0 * B * nh * hd * T * (T + 1) / 2)
-  with _Timed('attn_fwd', 4.0 * B * nh * hd * T * (T + 1) / 2):
-    _lib.check(_lib.load().plm_attn_fwd(_p(qkv_rot), _p(doc_start), _p(out), _p(lse), B, T, nh, hd, _stream()), 'plm_attn_fwd')
+  _hook('attn_fwd', attn_flops(B, T, nh, hd))  # the reducer's clock only needs an estimate: no device reduction on the launch path
+  with _Timed('attn_fwd', attn_flops(B, T, nh, hd, doc_start) if PROFILE is not None else 0.0):
+    _lib.check(_lib.load().plm_attn_fwd(_p(qkv_rot), _p(doc_start), _p(plan), _p(out), _p(lse), B, T, nh, hd, _stream()), 'plm_attn_fwd')
   return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, rope_cos, rope_sin, B, T, nh, doc_start=None):
+def attn_bwd(qkv, out, dout, lse, rope_cos, rope_sin, B, T, nh, doc_start=None, plan=None):
   _need(dout, BF16, 'attn_bwd.dout', 2)
   hd = qkv.shape[1] // (3 * nh)
+  if doc_start is not None and plan is None:
+    plan = attn_doc_plan(doc_start, nh)
   dqkv = torch.empty_like(qkv)
   delta = torch.empty((B, nh, T), dtype=F32, device=qkv.device)
-  _hook('attn_bwd', 8.0 * B * nh * hd * T * (T + 1) / 2)
-  with _Timed('attn_bwd', 8.0 * B * nh * hd * T * (T + 1) / 2):
-    _lib.check(_lib.load().plm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(rope_cos), _p(rope_sin), _p(doc_start),
+  _hook('attn_bwd', 2.0 * attn_flops(B, T, nh, hd))
+  with _Timed('attn_bwd', 2.0 * attn_flops(B, T, nh, hd, doc_start) if PROFILE is not None else 0.0):
+    _lib.check(_lib.load().plm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(rope_cos), _p(rope_sin), _p(doc_start), _p(plan),
                                         _p(dqkv), _p(delta), B, T, nh, hd, _stream()), 'plm_attn_bwd')
   return dqkv
 
@@ -473,8 +511,9 @@ def ce_fwd_bwd_(logits, targets, grad_scale, V=None):
   M, ld = logits.shape
   V = ld if V is None else V
   rows = torch.empty((M,), dtype=F32, device=logits.device)
-  _lib.check(_lib.load().plm_ce_fwd_bwd(_p(logits), _p(targets), _p(rows), M, V, ld, float(grad_scale), _stream()),
-             'plm_ce_fwd_bwd')
+  with _Timed('hbm:ce_fwd_bwd', 4.0 * M * V):  # one read + one write of the bf16 logits
+    _lib.check(_lib.load().plm_ce_fwd_bwd(_p(logits), _p(targets), _p(rows), M, V, ld, float(grad_scale), _stream()),
+               'plm_ce_fwd_bwd')
   return rows
 
 

@@ -339,6 +339,8 @@ class Transformer(nn.Module):
       raise ValueError(f'sequence length {T} exceeds cfg.seq_len {self.cfg.seq_len}')
     rope = self._rope(x.device)
     doc_start = self._doc_start(attn_mask, B, T)
+    if doc_start is not None:
+      doc_start = Fn.DocMask(doc_start, self.cfg.n_heads)  # + the plan: one small launch per batch, shared by every layer's attention launches
     self.refresh_shadows()
     h = self.embed_tokens(x).view(B * T, self.cfg.dim)
     branch = None

@@ -311,3 +311,57 @@ def test_160m_batch32_launch_vs_bf16_emulating_oracle(ops):
   bad = {n: e for n, e in worst.items() if e > 2.5e-2}
   assert not bad, bad
   _l2_report('160M 16 x pair gradients vs bf16-emulating oracle', got, eg, 2.5e-2, 2e-2)
+
+
+# --------------------------------------------------------------------------------------
+# (d) the reference's configs AS SHIPPED: seq_len 2048 for the 160M model
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,masked', [(32, False), (8, True)])
+def test_160m_seq2048_as_shipped_vs_oracle(ops, B, masked):
+  """config/config.yaml:9,33 (seq_len 2048, micro_batch_size 32: M = 65536 token rows, logits [65536, 50304] = 3.3e9 elements - the first
+  shape in the suite whose element and byte offsets pass 2^31 / 2^32; the sort-based embedding backward sits exactly on its M <= 65536 limit)
+  and config_doc_mask.yaml:9,35 (seq_len 2048, micro_batch_size 8, document masks: the plan's split items at 32-tile costs).  The batch is ONE
+  pair of sequences repeated B / 2 times, so the batch-mean loss and gradients ARE the pair's (fp32 oracle, one fwd+bwd of 2 x 2048 tokens
+  on the CPU) while every kernel runs the shipped config's launch.  Loss within 1e-4, all 75 gradients (rel-to-max, relative L2 per class,
+  projection coefficient), two runs bit-equal."""
+  import plainlm_amd as P
+  T = 2048
+  ocfg = O.OracleConfig(vocab_size=V160, seq_len=T, dim=768, n_layers=12, n_heads=12)
+  w = O.init_params(ocfg, seed=5)
+  rng = np.random.default_rng(99)
+  pair = torch.from_numpy(rng.integers(0, V160, size=(2, T + 1)))
+  tok = pair.repeat(B // 2, 1)
+  ids, tgt = tok[:, :T].contiguous(), tok[:, 1:].contiguous()
+  ds_pair = O.doc_start_from_lengths(_random_docs(2, T, 41, mean_len=512), T) if masked else None
+  ds = ds_pair.repeat(B // 2, 1).contiguous().cuda() if masked else None
+
+  def run():
+    m = P.Transformer(P.ModelConfig(vocab_size=V160, seq_len=T, dim=768, expand=8 / 3, n_layers=12, n_heads=12, mlp='glu'))
+    m.load_state_dict(w)
+    m = m.cuda()
+    m.enable_main_grad()
+    m.sink.begin_window()
+    loss = m.loss(ids.cuda(), tgt.cuda(), ds)
+    loss.backward()
+    m.attach_grads()
+    got = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    lg = loss.item()
+    del m, loss
+    torch.cuda.empty_cache()
+    return lg, got
+
+  lg, got = run()
+  lg2, got2 = run()
+  assert lg == lg2 and all(torch.equal(got[n], got2[n]) for n in got), 'two runs of the same step differ'
+  del got2
+  oloss, og = O.loss_and_grads(w, ocfg, pair[:, :T], pair[:, 1:], ds_pair)
+  rel = abs(lg - oloss.item()) / abs(oloss.item())
+  print(f'160M seq 2048 batch {B}{" doc masks" if masked else ""}: loss gpu {lg:.6f} cpu {oloss.item():.6f} rel {rel:.2e}')
+  assert rel <= LOSS_RTOL
+  assert len(got) == 75
+  worst = {n: relerr(got[n], og[n]) for n in got}
+  top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+  print('gradients vs fp32 oracle (rel-to-max), worst five:', [(n, f'{e:.1e}') for n, e in top])
+  bad = {n: e for n, e in worst.items() if e > 6e-2}
+  assert not bad, bad
+  _l2_report(f'160M seq 2048 batch {B} gradients vs fp32 oracle', got, og, 3.5e-2, 3e-2)

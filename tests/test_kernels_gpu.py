@@ -586,6 +586,136 @@ def test_attention_fwd_bwd(ops, B, T, nh, masked):
   close(dq, gq, 2e-2, 'attention dQ')
 
 
+def _plan_ref(ds, T, nh, split_min=8):
+  """numpy restatement of the plan (include/plainlm_hip.h, attn_common.h): header counts, doc_end, and the two item lists - the n / 4 heaviest
+  tiles with cost >= split_min as two 64-row halves when the grid is resident at once - in stable order of expected duration."""
+  B = ds.shape[0]
+  nt = (T + 127) // 128
+  n = B * nt
+  de = np.empty((B, T), dtype=np.int64)
+  for b in range(B):
+    for j in range(T):
+      later = np.nonzero(ds[b, j + 1:] > j)[0]
+      de[b, j] = j + 1 + later[0] if len(later) else T
+  up = lambda x: (x + 63) // 64
+  tiles = [[], []]  # per list: (b, r0, cost, (cost0, bound0), (cost1, bound1), whole-tile bound)
+  for b in range(B):
+    for t in range(nt):
+      r0, r1 = t * 128, min(t * 128 + 64, T - 1)
+      lo0, lo1 = int(ds[b, r0]) // 64, int(ds[b, r1]) // 64
+      hi0, hi1 = up(min(T, r0 + 64)), up(min(T, r0 + 128))
+      e0, e1 = up(int(de[b, min(r0 + 63, T - 1)])), up(int(de[b, min(r0 + 127, T - 1)]))
+      tiles[0].append((b, r0, hi1 - lo0, (hi0 - lo0, lo0), (hi1 - lo1, lo1), lo0))
+      tiles[1].append((b, r0, e1 - r0 // 64, (e0 - r0 // 64, e0), (e1 - (r0 + 64) // 64, e1), e1))
+  may_split = split_min > 0 and n * nh <= 1024 and n <= 768
+  lists = []
+  for l, tl in enumerate(tiles):
+    by_cost = sorted(range(n), key=lambda i: (-tl[i][2], i))
+    split = {i for k, i in enumerate(by_cost) if may_split and l == 0 and k < n // 4 and tl[i][2] >= split_min and tl[i][1] + 64 < T}  # key tiles are never split
+    items = []  # (est, tile, half, record)
+    for i, (b, r0, c, h0, h1, wb) in enumerate(tl):
+      if i in split:
+        for a, (ca, ba) in enumerate((h0, h1)):
+          items.append(((ca + 1) // 2 + 1, i, a, (b, r0 + 64 * a, ba, (1 << 30) | ca)))
+      else:
+        items.append((c, i, 0, (b, r0, wb, c)))
+    items.sort(key=lambda it: (-it[0], it[1], it[2]))
+    recs = [it[3] for it in items]
+    lists.append(recs)
+  return de, lists[0], lists[1]
+
+
+@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (3, 200, 1), (8, 1024, 12), (2, 2048, 16), (5, 836, 3), (32, 1024, 12)])
+def test_attention_doc_plan(ops, B, T, nh):
+  """plm_attn_doc_plan against its numpy restatement: header, doc_end[], both item lists (which tiles are split, bounds, order)."""
+  ds = O.doc_start_from_lengths(_random_docs(B, T, 3 * T + B), T)
+  plan = ops.attn_doc_plan(ds.cuda(), nh).cpu().numpy()
+  de, iq, ik = _plan_ref(ds.numpy(), T, nh)
+  n = B * ((T + 127) // 128)
+  cap = n + n // 4
+  pq = (8 + B * T + 3) // 4 * 4
+  assert plan.shape[0] == pq + 8 * cap
+  assert plan[0] == len(iq) and plan[1] == len(ik) and (plan[2:8] == 0).all()
+  assert np.array_equal(plan[8:8 + B * T].reshape(B, T), de)
+  assert np.array_equal(plan[pq:pq + 4 * len(iq)].reshape(-1, 4), np.array(iq))
+  assert np.array_equal(plan[pq + 4 * cap:pq + 4 * cap + 4 * len(ik)].reshape(-1, 4), np.array(ik))
+  again = ops.attn_doc_plan(ds.cuda(), nh).cpu().numpy()
+  live = np.r_[0:8 + B * T, pq:pq + 4 * len(iq), pq + 4 * cap:pq + 4 * cap + 4 * len(ik)]
+  assert np.array_equal(plan[live], again[live])
+
+
+@pytest.mark.parametrize('kind', ['one_doc', 'singletons', 'tile_aligned_64', 'tile_aligned_128', 'off_by_one', 'geometric_256', 'long_then_short'])
+def test_attention_doc_mask_structures(ops, kind):
+  """Document layouts that sit on the kernels' segment boundaries (a wave's idle / masked / unmasked tile classes, the per-lane thresholds,
+  the plan's bounds): one document per row (== causal), one-token documents, documents that start exactly on / one off 64- and 128-row tile
+  edges, the bench's geometric lengths, a long document followed by short ones.  Forward + backward vs the oracle, two runs bit-equal,
+  and the plan-less call (plan built inside ops) gives the same bits."""
+  B, T, nh = 2, 512, 2
+  rng = np.random.default_rng(5)
+  if kind == 'one_doc':
+    docs = [[T + 1]] * B
+  elif kind == 'singletons':
+    docs = [[1] * (T + 1)] * B
+  elif kind == 'tile_aligned_64':
+    docs = [[64] * 8 + [1], [192, 64, 128, 128, 1]]
+  elif kind == 'tile_aligned_128':
+    docs = [[128, 256, 128, 1], [256, 256, 1]]
+  elif kind == 'off_by_one':
+    docs = [[63, 65, 127, 129, 128, 1], [1, 127, 1, 255, 129]]
+  elif kind == 'geometric_256':
+    docs = []
+    for _ in range(B):
+      lens, tot = [], 0
+      while tot < T + 1:
+        n = int(min(rng.geometric(1.0 / 256.0), T + 1 - tot))
+        lens.append(n)
+        tot += n
+      docs.append(lens)
+  else:
+    docs = [[400, 30, 30, 30, 23], [7, 500, 6]]
+  assert all(sum(d) == T + 1 for d in docs)
+  g = torch.Generator().manual_seed(len(kind))
+  d = nh * 64
+  qkv = bf(torch.randn(B * T, 3 * d, generator=g))
+  dout = bf(torch.randn(B * T, d, generator=g))
+  ds = O.doc_start_from_lengths(docs, T)
+  leaf = qkv.float().requires_grad_(True)
+  ref = _attn_ref(leaf, B, T, nh, ds)
+  ref.backward(dout.float())
+  cos, sin = (t.cuda() for t in O.rope_table(64, T))
+  dsg = ds.cuda()
+  plan = ops.attn_doc_plan(dsg, nh)
+  qrot = ops.rope_qk_(qkv.cuda(), cos, sin, B, T, nh)
+  out, lse = ops.attn_fwd(qrot, B, T, nh, dsg, plan)
+  close(out.float(), ref, 1.6e-2, f'attention out [{kind}]')
+  dqkv = ops.attn_bwd(qrot, out, dout.cuda(), lse, cos, sin, B, T, nh, dsg, plan)
+  for name, got, want in zip('qkv', dqkv.split(d, dim=1), leaf.grad.split(d, dim=1)):
+    if kind == 'singletons' and name != 'v':  # one visible key per row: dS = P (dP - delta) is exactly zero, so dQ = dK = 0 up to bf16(O)'s rounding in delta
+      assert got.float().abs().max().item() <= 1e-2 * leaf.grad[:, 2 * d:].abs().max().item()
+      continue
+    close(got.float(), want, 2e-2, f'attention d{name} [{kind}]')
+  out2, lse2 = ops.attn_fwd(qrot, B, T, nh, dsg)
+  dqkv2 = ops.attn_bwd(qrot, out2, dout.cuda(), lse2, cos, sin, B, T, nh, dsg)
+  assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(dqkv, dqkv2)
+  if kind == 'one_doc':  # a single document per row is the causal mask (SURVEY section 8a, A11): the two kernel families agree closely
+    outc, _ = ops.attn_fwd(qrot, B, T, nh)
+    close(out.float(), outc.float(), 8e-3, 'one document per row vs the causal kernels')
+
+
+def test_attention_doc_requires_plan_at_the_c_abi(ops):
+  """The C entry points refuse a document mask without its plan (no silent slow path)."""
+  import ctypes as C
+  from plainlm_amd import _lib
+  B, T, nh = 1, 128, 1
+  qkv = torch.zeros(B * T, 192, dtype=torch.bfloat16, device='cuda')
+  ds = torch.zeros(B, T, dtype=torch.int32, device='cuda')
+  out = torch.empty(B * T, 64, dtype=torch.bfloat16, device='cuda')
+  lse = torch.empty(B, nh, T, device='cuda')
+  p = lambda t: C.c_void_p(t.data_ptr())
+  rc = _lib.load().plm_attn_fwd(p(qkv), p(ds), C.c_void_p(0), p(out), p(lse), B, T, nh, 64, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+  assert rc != 0 and b'plan' in _lib.load().plm_last_error_string()
+
+
 def test_rope_qk_golden(ops, golden_dir):
   """In-place RoPE against the reference's apply_rotary_emb_complex_like outputs."""
   z = {k: torch.from_numpy(v) for k, v in np.load(f'{golden_dir}/ops.npz').items() if k.startswith('rope_')}

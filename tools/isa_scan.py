@@ -21,7 +21,7 @@ def main():
   a = ap.parse_args()
   src = os.path.join(ROOT, 'plainlm_amd', 'csrc', a.file)
   with tempfile.TemporaryDirectory() as td:
-    extra = ['-fno-slp-vectorize'] if a.file in ('attn_causal.hip',) else []  # as csrc/Makefile builds them
+    extra = ['-fno-slp-vectorize'] if a.file in ('attn_causal.hip', 'attn_doc.hip') else []  # as csrc/Makefile builds them
     r = subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + extra + ['-c', src, '-o', os.path.join(td, 'x.o'), '-save-temps=obj'], cwd=td, capture_output=True, text=True)
     if r.returncode != 0:
       sys.exit(r.stderr[-2000:])

@@ -184,9 +184,22 @@ def main():
       ds = doc_start_from_lengths(docs, T).to(dev)
       pos = torch.arange(T, device=dev)[None, :]
       fl_m = float((4.0 * nh * 64 * (pos - ds + 1)).sum())  # visible (query, key) pairs x 2 matmuls x 2 flop x head_dim
-      out_m, lse_m = ops.attn_fwd(qkv, B, T, nh, ds)
-      rec('attn fwd (doc masks, mean length 256; flops of the visible pairs)', timeit(lambda: ops.attn_fwd(qkv, B, T, nh, ds), a.iters), flops=fl_m)
-      rec('attn bwd (doc masks)', timeit(lambda: ops.attn_bwd(qkv, out_m, dout, lse_m, cos, sin, B, T, nh, ds), a.iters), flops=2.0 * fl_m)
+      import os
+      from plainlm_amd import _lib
+      rec('attn doc plan (once per batch)', timeit(lambda: ops.attn_doc_plan(ds, nh), a.iters))
+      # the shipped kernels, and the same without heavy tiles split into 64-row items (same process, same box)
+      for tag, env in (('', {}), (' [no split]', {'PLM_ATTN_DOC_SPLIT_MIN': '0'})):
+        for k in ('PLM_ATTN_DOC_SPLIT_MIN',):
+          os.environ.pop(k, None)
+        os.environ.update(env)
+        _lib.load().plm_reload_env()
+        plan = ops.attn_doc_plan(ds, nh)
+        out_m, lse_m = ops.attn_fwd(qkv, B, T, nh, ds, plan)
+        rec('attn fwd (doc masks, mean length 256; flops of the visible pairs)' + tag, timeit(lambda: ops.attn_fwd(qkv, B, T, nh, ds, plan), a.iters), flops=fl_m)
+        rec('attn bwd (doc masks)' + tag, timeit(lambda: ops.attn_bwd(qkv, out_m, dout, lse_m, cos, sin, B, T, nh, ds, plan), a.iters), flops=2.0 * fl_m)
+      for k in ('PLM_ATTN_DOC_SPLIT_MIN',):
+        os.environ.pop(k, None)
+      _lib.load().plm_reload_env()
 
   if want('hbm'):
     x = torch.randn(M, d, device=dev)
