@@ -339,7 +339,7 @@ def test_no_register_spills_in_the_persistent_gemm_kernels():
       assert m and int(m.group(1)) <= 16, (k, span)
     else:
       assert meta['sspill'] == 0, (k, meta)
-    if 'gemm_nt_big_kernel' in k and k.endswith('false, false, false, false>'):  # plain and HYB instantiations: the K loop never drains the DMA ring
+    if 'gemm_nt_big_kernel' in k and re.search(r', (true|false), false, false, false>$', k):  # plain AND stream-K (HYB) instantiations - no GLU / GLUB / RoPE epilogue: the K loop never drains the DMA ring
       m = re.search(r'unconditional vmcnt\(0\): (\d+)', span)
       assert m and int(m.group(1)) <= 1, (k, span)
 
@@ -354,7 +354,7 @@ def test_register_budget_of_the_attention_and_128x128_gemm_kernels():
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   seen = 0
-  for f in ('attn_causal.hip', 'attn.hip', 'gemm.hip'):
+  for f in ('attn_causal.hip', 'attn_doc.hip', 'gemm.hip'):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'isa_scan.py'), f], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()
@@ -369,5 +369,8 @@ def test_register_budget_of_the_attention_and_128x128_gemm_kernels():
           assert meta['vspill'] <= 3 and meta['sspill'] <= 14 and meta['scratch'] <= 16, (name, meta)
         else:
           assert meta['vspill'] == 0 and meta['sspill'] == 0 and meta['scratch'] == 0, (name, meta)
-  assert seen >= 18, seen
+        if 'attn_fwd_doc_kernel' in name or 'attn_bwd_dq_doc_kernel' in name:
+          # three workgroups per CU (768 resident workgroups = the whole grid of config_doc_mask.yaml's micro-batch): 512 / 3 registers per lane
+          assert meta['vgpr'] <= 168, (name, meta)
+  assert seen >= 16, seen
 
