@@ -390,11 +390,19 @@ def main():
     # The contract's timed region runs on the SIMPLEST data plane - the uncapped root communicator (a plain ncclCommInitRank), ncclAllReduce,
     # no CU reserve: the path least likely to fail in a first multi-GPU contact, so that whatever happens afterwards (ncclCommSplit, capped
     # collectives, the other algorithm) a measurement exists.  The capped communicators are created and every alternative - including the
-    # engine's default, cap PLM_COMM_CUS = 16 with the tail bucket on the root - is measured afterwards, under a watchdog.
+    # caps 8 / 16 (and PLM_COMM_CUS if set) with the tail bucket on either communicator - is measured afterwards, under a watchdog.
+    # PLM_BENCH_FIRST_ALT='algo,cap,tail' (e.g. 'allreduce,16,1'; tools/ddp_whatif.sh) times another data plane first - a what-if knob, the
+    # driver's run never sets it.
     comms = ddp.make_comm_set(device, a.comm, caps=[])
     alt_default = {'algo': os.environ.get('PLM_COMM_ALGO') or 'allreduce', 'cap': 0, 'tail': False}
-    reducer = ddp.GradReducer(flat, params, model._grad_spans, comms[0], bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
-                              reserve_cus=0, writers=model.grad_writers(), comm_tail=None, groups=model.grad_groups(),
+    first_alt = os.environ.get('PLM_BENCH_FIRST_ALT')
+    if first_alt:
+      f_algo, f_cap, f_tail = (first_alt.split(',') + ['0', '0'])[:3]
+      alt_default = {'algo': f_algo, 'cap': int(f_cap), 'tail': f_tail.strip().lower() in ('1', 'true', 'tail')}
+      ddp.add_capped_comms(comms, [alt_default['cap']])
+    c0, c0_tail, c0_reserve = ddp.pick_comms(comms, cap=alt_default['cap'], tail=alt_default['tail'])
+    reducer = ddp.GradReducer(flat, params, model._grad_spans, c0, bucket_cap_mb=a.bucket_mb, force=bool(force_reducer),
+                              reserve_cus=c0_reserve, writers=model.grad_writers(), comm_tail=c0_tail, groups=model.grad_groups(),
                               algo=alt_default['algo'])
     reducer.broadcast_params([p.data for p in params])
     model.sink.on_ready = reducer.param_ready

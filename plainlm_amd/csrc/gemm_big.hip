@@ -38,18 +38,30 @@ __device__ __forceinline__ int big_swz(int row, int chunk) { return row * 128 + 
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+#ifdef PLM_DBG_DRAIN  // the self-check build of tests/test_perf_guard_gpu.py (tools/perf_guard_selfcheck.sh): every counted wait drains the DMA ring
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 // vmcnt(flag ? N1 : N0) with a wave-uniform flag: s_waitcnt only takes an immediate, and the if / else form costs hipcc six scalar
 // instructions and two branches per wait (it routes the arms through a mask register)
 template <int N0, int N1>
 __device__ __forceinline__ void wait_vm_sel(int flag) {
+#ifdef PLM_DBG_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return;
+#endif
   asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%1)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(%2)\n2:" ::"s"(flag), "n"(N0), "n"(N1)
                : "memory", "scc");
 }
 // three-way form: flag 0 -> N0, 1 -> N1, anything else -> N2
 template <int N0, int N1, int N2>
 __device__ __forceinline__ void wait_vm_sel3(int flag) {
+#ifdef PLM_DBG_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return;
+#endif
   asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%1)\n\ts_branch 3f\n1:\n\ts_cmp_lg_u32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(%2)\n\t"
                "s_branch 3f\n2:\n\ts_waitcnt vmcnt(%3)\n3:" ::"s"(flag), "n"(N0), "n"(N1), "n"(N2)
                : "memory", "scc");

@@ -27,10 +27,14 @@ from . import _lib
 # the forward pass, the lm_head backward and every GEMM behind a finished collective keep all 256 CUs.  Sizing: 649 MB of fp32
 # gradients per ~20 ms of backward is 32 GB/s of algorithm bandwidth = 57 GB/s of bus bandwidth at 8 ranks; one RCCL channel moves
 # 15-25 GB/s over an xGMI link.  The SIZE of the reserve hardly matters to the GEMMs (4 vs 16 CUs: 0.1-0.2 ms per step,
-# profiles/r04_ddp_whatif.txt), so until a multi-GPU run has compared them the default stays at the generous 16 (round 4 had
-# lowered it to 8 on a back-of-envelope figure) - and bench.py measures {0, 8, 16} itself when it runs on more than one
-# GPU (autotune, below).
-COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '16'))
+# profiles/r04_ddp_whatif.txt).
+# DEFAULT: NO cap and NO reserve (round 6).  None of this machinery has ever run with more than one RCCL rank (no multi-GPU box has been
+# available to this build), so the engine's first contact is the most travelled path of the library - the uncapped root communicator,
+# ncclAllReduce, every CU left to the GEMMs - exactly what bench.py times first.  A capped child communicator + the GEMM-side reserve are
+# opt-in: PLM_COMM_CUS=<workgroups> (with PLM_COMM_TAIL / PLM_COMM_ALGO) - the variables through which the winner of bench.py's autotune
+# table (`comm.alternatives` of a --gpus N line: {algo, cap, tail}) is handed to HipEngine: cap -> PLM_COMM_CUS, algo -> PLM_COMM_ALGO,
+# tail -> PLM_COMM_TAIL (1 / 0).
+COMM_CUS = int(os.environ.get('PLM_COMM_CUS', '0'))
 # Prior rates (flop/s) by kernel family for the reducer's clock of enqueued GPU time.  They only fix the RATIOS between families:
 # the clock is rescaled every step by measured / estimated time of the previous step (HIP events around begin() ... finish()), so a
 # slower or faster box, or the 420M shapes, do not drift the windows away from the collectives they follow.
@@ -41,7 +45,6 @@ _FAMILY_RATE = {'gemm_nt': 1.15e15, 'gemm_nt_fused': 0.85e15, 'gemm_tn': 1.15e15
 #            the clock scale - never change again: from that step on every rank takes the same GEMM plans in every step.
 #   'model'  - bytes / PLM_COMM_MODEL_GBPS (implied when that variable is set): no measurement at all; the only mode in which a
 #            data-parallel run is bit-reproducible RUN TO RUN (the plans - stream-K / split-K partitions - depend on the windows).
-#   'ema'    - round 4's behaviour: follow the previous step's measurement forever (plans may change from step to step).
 FREEZE_AFTER = 3
 # The caps are per communicator (ncclConfig_t.maxCTAs through plm_comm_split); NCCL_MAX_NCHANNELS is never set by this package
 # (round 4 exported it process-wide as belt and braces, which also throttled the exposed tail bucket).  The communicator
@@ -233,8 +236,8 @@ class GradReducer:
     model_gbps = os.environ.get('PLM_COMM_MODEL_GBPS')
     self.model_gbps = float(model_gbps) if model_gbps else None
     self.window_mode = 'model' if self.model_gbps else os.environ.get('PLM_COMM_WINDOWS', 'frozen')
-    if self.window_mode not in ('model', 'frozen', 'ema'):
-      raise ValueError(f"PLM_COMM_WINDOWS={self.window_mode!r}: expected 'frozen', 'model' or 'ema'")
+    if self.window_mode not in ('model', 'frozen'):
+      raise ValueError(f"PLM_COMM_WINDOWS={self.window_mode!r}: expected 'frozen' or 'model'")
     self._bucket_bytes = [(hi - lo) * 4 for lo, hi, _ in self.buckets]
     self.reset_windows()
     # the dW queue (functional.GradSink) is flushed at bucket boundaries once it holds this many bytes of gradients
@@ -296,10 +299,10 @@ class GradReducer:
     """Top of a communicating step: fold the measurements of earlier steps that have finished on the GPU into the window table and
     the clock scale.  'frozen' mode: at the top of step FREEZE_AFTER + 1 (the same step on every rank - the agreement is a collective)
     the host waits ONCE for the steps it has enqueued, folds them, the ranks agree on the elementwise maximum, and nothing changes
-    any more; 'ema' keeps following; 'model' never measures."""
+    any more; 'model' never measures."""
     if self.frozen:
       return
-    freeze_now = self.window_mode == 'frozen' and self.sync_steps >= FREEZE_AFTER
+    freeze_now = self.sync_steps >= FREEZE_AFTER
     while self._hist and self._hist[0] is not self._cur:
       rec = self._hist[0]
       ends = [t1 for _, t1 in rec['buckets'].values()] + ([rec['span'][1]] if rec['span'] is not None else [])
@@ -483,7 +486,7 @@ def make_comm_set(device, backend=None, group=None, caps=None):
   differ between ranks (a failed creation) is agreed on the control plane, so the ranks always end up with the same set.
   backend 'torch' (or a failed direct set-up): {0: TorchDistComm} - torch.distributed has no per-communicator cap, the GEMM-side
   reserve is then the only knob."""
-  caps = [COMM_CUS] if caps is None else list(caps)
+  caps = ([COMM_CUS] if COMM_CUS > 0 else []) if caps is None else list(caps)  # default: the root alone (see COMM_CUS)
   world = dist.get_world_size(group) if dist.is_initialized() else 1
   rank = dist.get_rank(group) if dist.is_initialized() else 0
   backend = backend or os.environ.get('PLM_COMM', 'rccl' if torch.device(device).type == 'cuda' else 'torch')
@@ -596,12 +599,13 @@ def apply_alternative(reducer, comms, alt):
 
 def data_plane_alternatives(comms, first=None):
   """The alternatives bench.py's autotune measures on a communicator set: {all-reduce, reduce-scatter + all-gather} (direct RCCL only) x
-  {no reserve, 8, 16 CUs} x {tail buckets on the capped communicator, on the uncapped root} (only where the set has that cap); `first`
-  (the data plane already timed) is kept / put in front."""
+  {no reserve, every cap the set has a child communicator for, PLM_COMM_CUS if set} x {tail buckets on the capped communicator, on the
+  uncapped root} (only where the set has that cap); `first` (the data plane already timed) is kept / put in front."""
   direct = isinstance(comms[0], RcclComm)
+  caps = sorted({0, 8, 16} | {int(c) for c in comms} | ({COMM_CUS} if COMM_CUS > 0 else set()))  # 8 / 16 without a child: root + GEMM-side reserve
   alts = []
   for algo in (('allreduce', 'rsag') if direct else ('allreduce',)):
-    for cap in (0, 8, 16):
+    for cap in caps:
       for tail in ((False, True) if (cap and cap in comms) else (False,)):
         alts.append({'algo': algo, 'cap': cap, 'tail': tail})
   if first is not None and first not in alts:

@@ -208,8 +208,9 @@ class HipEngine(torch.nn.Module):
 
     self.reducer = None
     if dist.is_initialized() and dist.get_world_size() > 1:
-      # uncapped root communicator + a child capped at PLM_COMM_CUS workgroups for the buckets reduced while backward runs; the tail
-      # bucket (embed_tokens, ready when backward has ended) goes through the root
+      # default: the uncapped root communicator alone, ncclAllReduce, no CU reserve - the data plane bench.py times first (ddp.COMM_CUS).
+      # PLM_COMM_CUS=<n> adds a child capped at n workgroups for the buckets reduced while backward runs (the tail bucket - embed_tokens,
+      # ready when backward has ended - then goes through the root unless PLM_COMM_TAIL=0) and the same GEMM-side reserve
       comm, comm_tail, reserve = ddp.pick_comms(ddp.make_comm_set(device, comm_backend))
       self.reducer = ddp.GradReducer(flat, self.params, self.model._grad_spans, comm, bucket_cap_mb=bucket_cap_mb,
                                       writers=self.model.grad_writers(), comm_tail=comm_tail, reserve_cus=reserve,

@@ -150,6 +150,33 @@ def _worker(rank, world, port, out_dir, tied=False):
     assert calls_rs['n'] == 6 and calls['n'] - n0 == 3 * (ddp.FREEZE_AFTER + 1 + 2) * len(red.buckets)
     ddp.apply_alternative(red, comms, alts[win])
     assert red.comm is comm and red.comm_tail is None and red.algo == 'allreduce'
+  if not tied:
+    # A capped communicator whose ncclCommSplit fails on ONE rank must be dropped on EVERY rank (ddp.add_capped_comms agrees on the control
+    # plane): ranks that disagreed about which communicators exist would enter different collectives.  The direct-RCCL root is faked (no GPU
+    # here): its split() fails for cap 8 on rank 1 only; every rank must end with {0, 16}, the children created for the lost cap closed, and
+    # the alternatives of the autotune table must then carry cap 8 without its tail variant (no child: root + GEMM-side reserve).
+    class FakeRccl(ddp.RcclComm):
+      closed = []
+
+      def __init__(self, r, cap=0):  # no library, no handle
+        self.rank, self.world_size, self.max_ctas, self.backend = r, world, cap, 'rccl-direct'
+
+      def split(self, max_ctas=0):
+        if max_ctas == 8 and self.rank == 1:
+          raise RuntimeError('simulated ncclCommSplit failure')
+        return FakeRccl(self.rank, max_ctas)
+
+      def close(self):
+        FakeRccl.closed.append(self.max_ctas)
+
+    fake_set = ddp.add_capped_comms({0: FakeRccl(rank)}, (8, 16))
+    assert sorted(fake_set) == [0, 16] and fake_set[16].max_ctas == 16, sorted(fake_set)
+    assert FakeRccl.closed == ([] if rank == 1 else [8])  # the ranks whose split had succeeded gave their child back
+    alts = ddp.data_plane_alternatives(fake_set)
+    assert {'algo': 'allreduce', 'cap': 8, 'tail': False} in alts and {'algo': 'allreduce', 'cap': 8, 'tail': True} not in alts
+    assert {'algo': 'rsag', 'cap': 16, 'tail': True} in alts
+    assert ddp.pick_comms(fake_set) == (fake_set[0], None, 0)  # the engine's default first contact: root, no tail communicator, no reserve
+    assert ddp.pick_comms(fake_set, cap=16) == (fake_set[16], fake_set[0], 16) and ddp.pick_comms(fake_set, cap=8) == (fake_set[0], None, 8)
   torch.save({'params': flat_p.clone(), 'grads': flat_g.clone()}, os.path.join(out_dir, f'r{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()

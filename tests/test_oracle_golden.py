@@ -169,6 +169,37 @@ def test_engine_loss_sequence(mdl, golden_dir):
   _close(eng.params['embed_tokens.weight'][:16], en['final:embed_rows'], 5e-5)
 
 
+def _cfg1_checksums(params):
+  return np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in params.values()])
+
+
+def test_engine_cfg1_literal_shape(golden_dir):
+  """BASELINE configs[0] / SURVEY section 8c at its literal shape - 2 layers, d = 128, 2 heads, seq 128, V = 50 280, micro-batch 1 x
+  accumulation 4, 6 optimizer steps - as the REFERENCE engine ran it on the CPU (tests/golden/make_cfg1.py): the oracle engine reproduces the 24
+  micro-step losses, the 6 learning rates, all parameter norms per step and the final-weight slices.  The initial weights are
+  init_params(seed 7) on both sides; their checksums are part of the fixture."""
+  z = _load(golden_dir, 'cfg1.npz')
+  cfg = O.OracleConfig(vocab_size=50280, seq_len=128, dim=128, n_layers=2, n_heads=2)
+  w = O.init_params(cfg, seed=7)
+  np.testing.assert_allclose(_cfg1_checksums(w), z['init_checksums'].numpy(), rtol=1e-12)
+  eng = O.OracleEngine(w, cfg, lr=3e-3, weight_decay=0.1, beta1=0.9, beta2=0.95, grad_clip=1.0, accum=4, steps_budget=6, warmup_steps=2)
+  losses, lrs, norms = [], [], []
+  for i in range(z['tokens'].shape[0]):
+    losses.append(eng.step({'input_ids': z['tokens'][i]}).item())
+    if (i + 1) % 4 == 0:
+      lrs.append(eng.lr)
+      norms.append([eng.params[n].norm().item() for n in O.param_names(cfg)])
+  np.testing.assert_allclose(losses, z['losses'].numpy(), rtol=2e-6)
+  np.testing.assert_allclose(lrs, z['lrs'].numpy(), rtol=1e-12)
+  np.testing.assert_allclose(norms, z['param_norms'].numpy(), rtol=5e-6)
+  rows = z['rows']
+  _close(eng.params['embed_tokens.weight'][rows], z['final:embed_rows'], 5e-5)
+  _close(eng.params['lm_head.weight'][rows], z['final:lm_head_rows'], 5e-5)
+  _close(eng.params['layers.1.mlp.fc2.weight'], z['final:layers.1.mlp.fc2.weight'], 5e-5)
+  _close(eng.params['layers.0.attn.w_qkv.weight'][:32], z['final:layers.0.attn.w_qkv.weight'], 5e-5)
+  _close(eng.params['out_norm.weight'], z['final:out_norm.weight'], 5e-6)
+
+
 # ---- bf16-emulating mode (oracle/cpu_ref_bf16.py) ----------------------------------------------------------------------
 def test_bf16_mode_without_rounding_equals_fp32_oracle(mdl):
   """The hand-written forward + backward of the emulating mode IS the reference's algorithm: with the bf16 rounding

@@ -1,0 +1,136 @@
+"""A performance regression is a failing test or it is invisible (round 4's spilling stream-K kernel was numerically perfect and 10-30 % slow
+for a whole round).  One `-m gpu` test: a dozen sections of the training step - the plain NT GEMM shapes at N = 768, lm_head forward, the
+grouped weight-gradient launch, the three fused GEMM epilogues, attention forward / backward (causal at the bench's batch, document masks at
+the reference's micro-batch), RMSNorm forward / backward, cross-entropy - are timed with HIP events and must run within 1 / 0.85 of the
+times committed in tests/perf_floors.json (microseconds per launch, the SLOWEST of the boxes sampled: the pool's boxes differ by 3-6 % on
+the same tree, so the guard fires on a 15 - 20 % regression of one section, not on a slow box).
+
+  python tests/test_perf_guard_gpu.py --record      prints this box's times as JSON (update perf_floors.json with the per-key MAXIMUM over boxes)
+  PLM_PERF_GUARD_LIB=tools/_lib_drain.so python -m pytest tests/test_perf_guard_gpu.py      the guard against another build of the library
+  tools/perf_guard_selfcheck.sh                     builds the library with every counted LDS-DMA wait of the persistent GEMMs draining the
+                                                    ring (-DPLM_DBG_DRAIN) and shows that this test fails on it
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLOORS = os.path.join(ROOT, 'tests', 'perf_floors.json')
+MARGIN = 0.85
+
+
+def _timeit(fn, iters=20, warmup=8, reps=3):
+  """median over `reps` of (HIP-event time of `iters` back-to-back launches / iters), microseconds"""
+  for _ in range(warmup):
+    fn()
+  torch.cuda.synchronize()
+  out = []
+  for _ in range(reps):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+      fn()
+    e.record()
+    torch.cuda.synchronize()
+    out.append(1e3 * s.elapsed_time(e) / iters)
+  return float(np.median(out))
+
+
+def _docs(B, T, seed):
+  rng = np.random.default_rng(seed)
+  out = []
+  for _ in range(B):
+    lens, tot = [], 0
+    while tot < T + 1:
+      n = int(min(rng.geometric(1.0 / 256.0), T + 1 - tot))
+      lens.append(n)
+      tot += n
+    out.append(lens)
+  return out
+
+
+def measure():
+  if os.environ.get('PLM_PERF_GUARD_LIB'):
+    from plainlm_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ['PLM_PERF_GUARD_LIB'])
+  from plainlm_amd import ops
+  from plainlm_amd.engine import doc_start_from_lengths
+  dev, BF = 'cuda', torch.bfloat16
+  B, T, d, nh, h, V = 32, 1024, 768, 12, 2048, 50280
+  M = B * T
+  g = torch.Generator(device=dev).manual_seed(1)
+  rnd = lambda *shape, scale=1.0: (torch.randn(*shape, device=dev, generator=g) * scale).to(BF)
+  t = {}
+  # plain NT launches at N = 768 (out-proj / fc2 forward, dX of fc1) and lm_head forward
+  for name, (m, n, k) in {'nt out fwd (M,768,768)': (M, d, d), 'nt fc2 fwd (M,768,2048)': (M, d, h), 'nt dX fc1 (M,768,4096)': (M, d, 2 * h),
+                          'nt head fwd (M,50280,768)': (M, V, d)}.items():
+    A, W = rnd(m, k), rnd(n, k, scale=0.02)
+    out = torch.empty(m, n if n % 64 == 0 else 50304, device=dev, dtype=BF)[:, :n] if n == V else torch.empty(m, n, device=dev, dtype=BF)
+    t[name] = _timeit(lambda: ops.gemm_nt(A, W, out=out), iters=10 if n == V else 20)
+    del A, W, out
+  # grouped weight-gradient launch: the four projections of three transformer blocks (what a data-parallel step queues per launch)
+  x, dy_qkv, dy_d, dy_h2, act = rnd(M, d), rnd(M, 3 * d), rnd(M, d), rnd(M, 2 * h), rnd(M, h)
+  probs = []
+  for _ in range(3):
+    probs += [(dy_qkv, x, torch.empty(3 * d, d, device=dev)), (dy_d, x, torch.empty(d, d, device=dev)), (dy_h2, x, torch.empty(2 * h, d, device=dev)),
+              (dy_d, act, torch.empty(d, h, device=dev))]
+  t['tn dW grouped (3 blocks)'] = _timeit(lambda: ops.gemm_tn_grouped([(a, b, c, False, None) for a, b, c in probs]), iters=5)
+  del probs, dy_qkv, dy_h2
+  # fused epilogues: w_qkv + RoPE, fc1 + SwiGLU, dX fc2 + SwiGLU backward
+  from plainlm_amd.transformer import rope_tables
+  cos, sin = (v.to(dev) for v in rope_tables(64, T))
+  wq, w1, w2t = rnd(3 * d, d, scale=0.02), rnd(2 * h, d, scale=0.02), rnd(h, d, scale=0.02)
+  t['nt qkv fwd + rope'] = _timeit(lambda: ops.qkv_rope(x, wq, cos, sin, B, T, nh))
+  t['nt fc1 fwd + swiglu'] = _timeit(lambda: ops.fc1_swiglu(x, w1))
+  u = ops.fc1_swiglu(x, w1)[0]
+  t['nt dX fc2 + swiglu bwd'] = _timeit(lambda: ops.fc2_dx_swiglu_bwd(dy_d, w2t, u))
+  del wq, w1, w2t, u, act
+  # attention: causal at the bench's batch, document masks at the reference's micro-batch (config_doc_mask.yaml:35)
+  qkv = rnd(M, 3 * d)
+  out, lse = ops.attn_fwd(qkv, B, T, nh)
+  t['attn fwd causal (32,1024,12)'] = _timeit(lambda: ops.attn_fwd(qkv, B, T, nh))
+  t['attn bwd causal (32,1024,12)'] = _timeit(lambda: ops.attn_bwd(qkv, out, dy_d, lse, cos, sin, B, T, nh))
+  Bm = 8
+  ds = doc_start_from_lengths(_docs(Bm, T, 7), T).to(dev)
+  plan = ops.attn_doc_plan(ds, nh)
+  q8, do8 = qkv[:Bm * T], dy_d[:Bm * T]
+  out_m, lse_m = ops.attn_fwd(q8, Bm, T, nh, ds, plan)
+  t['attn fwd doc masks (8,1024,12)'] = _timeit(lambda: ops.attn_fwd(q8, Bm, T, nh, ds, plan), iters=40)
+  t['attn bwd doc masks (8,1024,12)'] = _timeit(lambda: ops.attn_bwd(q8, out_m, do8, lse_m, cos, sin, Bm, T, nh, ds, plan), iters=40)
+  del qkv, out, lse
+  # HBM-bound: add + RMSNorm forward, RMSNorm backward with the residual-gradient add, cross-entropy in place
+  xf, w = torch.randn(M, d, device=dev, generator=g), torch.ones(d, device=dev)
+  t['add + rmsnorm fwd'] = _timeit(lambda: ops.rmsnorm_fwd(xf, w, 1e-6, branch=x))
+  _, y, rstd = ops.rmsnorm_fwd(xf, w, 1e-6)
+  t['rmsnorm bwd (+ residual gradient)'] = _timeit(lambda: ops.rmsnorm_bwd(y, xf, w, rstd, gin=xf, want_bf16=True, defer_dw=True))
+  logits = torch.empty(M, 50304, device=dev, dtype=BF)
+  logits.normal_(generator=g)
+  tgt = torch.randint(0, V, (M,), device=dev, generator=g)
+  t['cross-entropy fwd+bwd (M,50280)'] = _timeit(lambda: ops.ce_fwd_bwd_(logits, tgt, 1.0 / M, V=V), iters=5)
+  return {k: round(v, 2) for k, v in t.items()}
+
+
+@pytest.mark.gpu
+def test_kernel_sections_within_the_committed_floors():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  floors = json.load(open(FLOORS))['us_per_launch']
+  got = measure()
+  assert set(got) == set(floors), sorted(set(got) ^ set(floors))
+  print('section: measured us / committed floor us (ratio)')
+  slow = {}
+  for k, us in got.items():
+    print(f'  {k:40s} {us:9.1f} / {floors[k]:9.1f}  ({us / floors[k]:.2f})')
+    if us > floors[k] / MARGIN:
+      slow[k] = (us, floors[k])
+  assert not slow, f'sections slower than 1 / {MARGIN} x their committed time (measured us, floor us): {slow}'
+
+
+if __name__ == '__main__':
+  if '--record' in sys.argv:
+    sys.path.insert(0, ROOT)
+    print(json.dumps(measure()))
