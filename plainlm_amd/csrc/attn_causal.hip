@@ -48,7 +48,18 @@ static_assert(ATTN_DMA_PER_STAGE == 2 * 2, "stage() = two TileDma::issue calls o
 
 #define ATTN_DEFER_LOG2 8.0f
 #define PLM_ATTN_TRACE_SETTER plm_dbg_attn_trace_causal
-ATTN_TRACE_DECL()  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
+ATTN_TRACE_DECL()
+#ifdef PLM_ATTN_ONEPASS_ABLATION  // tools/attn_onepass_ablation.py: never in the shipped library
+static __device__ float* g_onepass_buf = nullptr;
+static __device__ int g_onepass_mode = 0;  // 0 off | 1 dS through LDS + the 4 extra MFMAs | 2 + fp32 atomics of the partial dQ
+extern "C" int plm_dbg_attn_onepass(float* buf, int mode) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_onepass_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_onepass_mode), &mode, sizeof(mode));
+}
+#define ONEPASS_LDS 8192
+#else
+#define ONEPASS_LDS 0
+#endif  // the running maximum is updated when a row's new maximum exceeds it by more than 2^8 (P <= 256)
 
 enum { QB_OFF = 0, QB_UM = 1, QB_MASK = 2 };  // a 32-row block on a key tile: above its diagonal / no mask needed / masked
 
@@ -600,6 +611,39 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(char* smem, const uint16_t* _
           dv[db] = mfma32(dotr[db][s2], pf[s2], dv[db]);   // dV^T[d][kv]
           dk[db] = mfma32(qtr[db][s2], dsf[s2], dk[db]);   // dK^T[d][kv]
         }
+#ifdef PLM_ATTN_ONEPASS_ABLATION
+      if (g_onepass_mode) {
+        // TIMING ONLY (tools/attn_onepass_ablation.py; results are garbage): what a one-pass backward would add to this block.  dS is in
+        // this kernel's layout (a lane owns a KEY); dQ contracts over keys, so dS has to change hands - through LDS into the A-operand
+        // layout (a lane owns a query) - then 4 MFMAs with K fragments from LDS (stood in for by the Q tile: same instructions) give the
+        // block's 32 x 64 partial dQ, which mode 2 adds to an fp32 [M, d] buffer with atomics (whole 128-byte row segments per half wave).
+        char* scr = smem + NST * STAGE + wave * 2048;
+        *reinterpret_cast<bf16x8_t*>(scr + lane * 32) = dsf[0];
+        *reinterpret_cast<bf16x8_t*>(scr + lane * 32 + 16) = dsf[1];
+        bf16x8_t at[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          at[s2] = join_tr(lds_read_tr16(scr + s2 * 1024 + (lane & 15) * 64 + (lane >> 4) * 8), lds_read_tr16(scr + s2 * 1024 + 512 + (lane & 15) * 32 + (lane >> 4) * 8));
+        f32x16_t dqp[2];
+        zero16(dqp[0]);
+        zero16(dqp[1]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dqp[db] = mfma32(at[s2], frag_cols(sQ, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane), dqp[db]);
+        if (g_onepass_mode == 2) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int q = min(qt0 + qb * 32 + mfma32_row(r, hi), T - 1);
+              atomicAdd(g_onepass_buf + ((int64_t)b * T + q) * dm + h * HD + db * 32 + l31, dqp[db][r]);
+            }
+        } else {
+          asm volatile("; partial dQ" ::"v"(dqp[0]), "v"(dqp[1]));
+        }
+      }
+#endif
     }
   };
 
@@ -674,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_causal_kernel(const uint
                                                                       const float* __restrict__ lse, const float* __restrict__ ndelta,
                                                                       const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                                       uint16_t* __restrict__ dqkv, int T, int nh) {
-  __shared__ __attribute__((aligned(1024))) char smem[NST * (2 * 8192 + 512)];
+  __shared__ __attribute__((aligned(1024))) char smem[NST * (2 * 8192 + 512) + ONEPASS_LDS];
   int kt, h, b;  // key tile 0 meets every query tile: heaviest first
   attn_block2<128>(T, nh, kt, h, b);
   attn_bwd_dkdv_body<NST, false>(smem, qkv, dout, lse, ndelta, rcos, rsin, nullptr, dqkv, T, nh, b, h, kt * 128, 0);
@@ -686,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_doc_kernel(const uint16_
                                                                    const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                                    const int32_t* __restrict__ header, const int32_t* __restrict__ doc_end,
                                                                    const int4* __restrict__ items, uint16_t* __restrict__ dqkv, int T, int nh) {
-  __shared__ __attribute__((aligned(1024))) char smem[NST * (2 * 8192 + 512)];
+  __shared__ __attribute__((aligned(1024))) char smem[NST * (2 * 8192 + 512) + ONEPASS_LDS];
   ATTN_TRACE_T(tr0);
   const int idx = blockIdx.x / nh, h = blockIdx.x - idx * nh;
   if (idx >= __builtin_amdgcn_readfirstlane(header[0])) return;
