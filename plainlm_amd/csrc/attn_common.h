@@ -72,6 +72,21 @@ struct TileDma {
   }
 };
 
+// LDS-DMA of a WAVE's own 32 rows x 64 d (4 KiB = 4 wave-instructions of 8 whole 128-byte rows) into a wave-private region with the tile
+// image's swizzle, and the fragment read that goes with it (row = lane & 31, chunk = 2 ks + hi).  The row fragments of the document-mask
+// kernels' prologues come this way: a fragment load straight from global memory is 32 rows x 32 bytes per instruction - four times the cache-line
+// requests for the same bytes, and at the reference's micro-batch all 3072 waves of the grid issue them in the same microsecond.
+__device__ __forceinline__ void rows_dma(char* region, const uint16_t* src, int64_t ld, int row0, int last_row, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (lane >> 3);
+    dma16_asm(src + (int64_t)min(row0 + row, last_row) * ld + rs_logical_chunk(row, lane & 7) * 8, region + i * 1024);
+  }
+}
+__device__ __forceinline__ bf16x8_t rows_frag(const char* region, int l31, int ks, int hi) {
+  return *reinterpret_cast<const bf16x8_t*>(region + rs_off(l31, ks * 2 + hi));
+}
+
 template <int N>
 __device__ __forceinline__ void attn_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(1024) void attn_doc_plan_kernel(const int32_t* __re
 template <int NST, bool SPLIT>
 __device__ __forceinline__ void attn_fwd_doc_body(char* smem, const uint16_t* __restrict__ qkv, const int32_t* __restrict__ doc_start,
                                                   uint16_t* __restrict__ out, float* __restrict__ lse, int T, int nh, int b, int h, int q0,
-                                                  int jt_lo) {
+                                                  int jt_lo, unsigned long long* trace_t = nullptr) {
   constexpr int KT = 64;
   constexpr int TILE = KT * 128;  // 8 KiB
   constexpr int NKB = SPLIT ? 1 : 2;  // 32-key blocks of a tile this wave takes
@@ -185,13 +185,16 @@ __device__ __forceinline__ void attn_fwd_doc_body(char* smem, const uint16_t* __
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i)
     if (i < n) stage(i, jt_lo + i);
-
+  // the wave's own Q rows: LDS-DMA into its quarter of the ring's last slot (nobody stages into it before the first tile's barrier), whole
+  // 128-byte rows instead of 32-byte fragments (rows_dma, attn_common.h); rows beyond T repeat row T - 1 (never stored)
+  char* qreg = smem + (NST - 1) * 2 * TILE + wave * 4096;
+  rows_dma(qreg, base, ld, qw0, T - 1, lane);
+  const int dsq = doc_start[(int64_t)b * T + min(qrow, T - 1)];  // rows beyond T repeat the last row (keeps the wave's bounds monotone)
+  asm volatile("; row data requested" ::"v"(dsq));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's rows and the first tiles have landed: nothing but LDS-DMA is counted from here on
   bf16x8_t qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
-  const int dsq = doc_start[(int64_t)b * T + min(qrow, T - 1)];  // rows beyond T repeat the last row (keeps the wave's bounds monotone)
-  asm volatile("; q fragments resident" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(dsq));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed (and with them the older DMA)
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = rows_frag(qreg, l31, ks, hi);
 
   f32x16_t o[2];
   zero16(o[0]);
@@ -287,11 +290,17 @@ __device__ __forceinline__ void attn_fwd_doc_body(char* smem, const uint16_t* __
       slot = (slot + 1 == NST) ? 0 : slot + 1;
     }
   };
+#ifdef PLM_ATTN_TRACE
+  if (trace_t) trace_t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
   run(ja, std::true_type{}, false);
   run(jm, std::true_type{}, true);
   run(jd, std::false_type{}, true);
   run(jd + 1, std::true_type{}, true);
   run(jt_hi, std::true_type{}, false);
+#ifdef PLM_ATTN_TRACE
+  if (trace_t) trace_t[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   char* stage_base = smem + (n % NST) * 2 * TILE;  // every wave has passed the last tile's barrier: slot n % NST is read by nobody any more
   if (SPLIT) {
@@ -349,11 +358,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_doc_kernel(const uint16_t* __
   const int4 it = items[idx];
   const int b = __builtin_amdgcn_readfirstlane(it.x), q0 = __builtin_amdgcn_readfirstlane(it.y), jt_lo = __builtin_amdgcn_readfirstlane(it.z);
   const int kc = __builtin_amdgcn_readfirstlane(it.w);
-  ATTN_TRACE_T(tr1);
-  if (kc >> DOC_KIND_SHIFT) attn_fwd_doc_body<NST, true>(smem, qkv, doc_start, out, lse, T, nh, b, h, q0, jt_lo);
-  else attn_fwd_doc_body<NST, false>(smem, qkv, doc_start, out, lse, T, nh, b, h, q0, jt_lo);
-  ATTN_TRACE_T(tr2);
-  ATTN_TRACE_END(0, idx, kc, tr0, tr1, tr2);
+#ifdef PLM_ATTN_TRACE
+  unsigned long long tt[2] = {0, 0};
+#else
+  unsigned long long* tt = nullptr;
+#endif
+  if (kc >> DOC_KIND_SHIFT) attn_fwd_doc_body<NST, true>(smem, qkv, doc_start, out, lse, T, nh, b, h, q0, jt_lo, tt);
+  else attn_fwd_doc_body<NST, false>(smem, qkv, doc_start, out, lse, T, nh, b, h, q0, jt_lo, tt);
+  ATTN_TRACE_END(0, idx, kc, tr0, tt[0], tt[1]);
 }
 
 // =============================================================================================
@@ -365,7 +377,8 @@ __device__ __forceinline__ void attn_bwd_dq_doc_body(char* smem, const uint16_t*
                                                      const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                      float* __restrict__ ndelta, const float* __restrict__ rcos,
                                                      const float* __restrict__ rsin, const int32_t* __restrict__ doc_start,
-                                                     uint16_t* __restrict__ dqkv, int T, int nh, int b, int h, int q0, int jt_lo) {
+                                                     uint16_t* __restrict__ dqkv, int T, int nh, int b, int h, int q0, int jt_lo,
+                                                     unsigned long long* trace_t = nullptr) {
   constexpr int KT = 64;
   constexpr int TILE = KT * 128;
   constexpr int NKB = SPLIT ? 1 : 2;
@@ -395,37 +408,35 @@ __device__ __forceinline__ void attn_bwd_dq_doc_body(char* smem, const uint16_t*
       dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
     }
   };
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)  // in front of the row loads: see the forward kernel
-    if (i < n) stage(i, jt_lo + i);
-
+  // Prologue: tile 0 goes to slot 0; the wave's own Q and O rows come by LDS-DMA (whole 128-byte rows: rows_dma, attn_common.h) into its
+  // quarters of slots 1 and 2 (three 4 KiB regions per wave do not fit beside tile 0: dO stays a fragment load); tiles 1 and 2 are staged
+  // behind the first barrier of the loop, when every wave has its fragments in registers.  Rows beyond T repeat row T - 1 (never stored).
+  if (n > 0) stage(0, jt_lo);
+  char* qreg = smem + 1 * 2 * TILE + wave * 4096;
+  char* oreg = smem + 2 * 2 * TILE + wave * 4096;
+  rows_dma(qreg, base, ld, qw0, T - 1, lane);
+  rows_dma(oreg, out + (int64_t)b * T * dm + h * HD, dm, qw0, T - 1, lane);
   bf16x8_t qf[4], dof[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int d0 = ks * 16 + hi * 8;
-    qf[ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + d0) : zero_bf16x8();
-    dof[ks] = qvalid ? ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + d0) : zero_bf16x8();
-  }
+  for (int ks = 0; ks < 4; ++ks) dof[ks] = qvalid ? ld_bf16x8(dout + ((int64_t)b * T + qrow) * dm + h * HD + ks * 16 + hi * 8) : zero_bf16x8();
   const int dsq = doc_start[(int64_t)b * T + min(qrow, T - 1)];
-  float Lq = 0.f, Dq;
+  float Lq = qvalid ? lse[((int64_t)b * nh + h) * T + qrow] : 0.f;  // base-2 LSE
+  asm volatile("; row data requested" ::"v"(dof[0]), "v"(dof[1]), "v"(dof[2]), "v"(dof[3]), "v"(Lq), "v"(dsq));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows and tile 0 have landed: nothing but LDS-DMA is counted from here on
+  float Dq;
   {
     float part_sum = 0.f;
-    if (qvalid) {
-      Lq = lse[((int64_t)b * nh + h) * T + qrow];  // base-2 LSE
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t o8 = ld_bf16x8(out + ((int64_t)b * T + qrow) * dm + h * HD + ks * 16 + hi * 8);
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = rows_frag(qreg, l31, ks, hi);
+      const bf16x8_t o8 = rows_frag(oreg, l31, ks, hi);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part_sum += bf2f(o8[e]) * bf2f(dof[ks][e]);
-      }
+      for (int e = 0; e < 8; ++e) part_sum += bf2f(o8[e]) * bf2f(dof[ks][e]);  // dO is zero for rows beyond T
     }
     float d_lo, d_hi;
-    half_pair(part_sum, d_lo, d_hi);  // rows beyond T hold zeros in both halves
-    Dq = d_lo + d_hi;                 // published (negated) in the epilogue: a store here would have to be waited for before the counted DMA waits
+    half_pair(part_sum, d_lo, d_hi);
+    Dq = d_lo + d_hi;  // published (negated) in the epilogue: a store here would have to be waited for before the counted DMA waits
   }
-  asm volatile("; q/dO fragments resident" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(dof[0]), "v"(dof[1]), "v"(dof[2]),
-               "v"(dof[3]), "v"(Lq), "v"(Dq), "v"(dsq));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed: nothing but LDS-DMA is counted from here on
 
   f32x16_t dq[2];
   zero16(dq[0]);
@@ -478,6 +489,11 @@ __device__ __forceinline__ void attn_bwd_dq_doc_body(char* smem, const uint16_t*
     }
   };
 
+  static_assert(NST == 3, "the prologue parks the wave's rows in slots 1 and 2");
+  // every wave has its row fragments in registers: slot 1 is free for tile 1 (tile 2 follows at the loop's first step, as always).  The loop's
+  // first wait then finds tile 0 landed (the prologue's vmcnt(0)) and at most tile 1's four instructions in flight - its usual count.
+  attn_barrier();
+  if (n > 1) stage(1, jt_lo + 1);
   int i = 0, slot = 0;
   auto run = [&](int jt_end, auto mask_tag, bool active) {
     for (; jt_lo + i < jt_end; ++i) {
@@ -491,11 +507,17 @@ __device__ __forceinline__ void attn_bwd_dq_doc_body(char* smem, const uint16_t*
       slot = (slot + 1 == NST) ? 0 : slot + 1;
     }
   };
+#ifdef PLM_ATTN_TRACE
+  if (trace_t) trace_t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
   run(ja, std::true_type{}, false);
   run(jm, std::true_type{}, true);
   run(jd, std::false_type{}, true);
   run(jd + 1, std::true_type{}, true);
   run(jt_hi, std::true_type{}, false);
+#ifdef PLM_ATTN_TRACE
+  if (trace_t) trace_t[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   char* stage_base = smem + (n % NST) * 2 * TILE;  // a slot nobody reads any more (see the forward kernel)
   if (SPLIT) {  // dQ = part 0's sum + part 1's, always in this order
@@ -543,11 +565,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_doc_kernel(const uint16_t*
   const int4 it = items[idx];
   const int b = __builtin_amdgcn_readfirstlane(it.x), q0 = __builtin_amdgcn_readfirstlane(it.y), jt_lo = __builtin_amdgcn_readfirstlane(it.z);
   const int kc = __builtin_amdgcn_readfirstlane(it.w);
-  ATTN_TRACE_T(tr1);
-  if (kc >> DOC_KIND_SHIFT) attn_bwd_dq_doc_body<NST, true>(smem, qkv, out, dout, lse, ndelta, rcos, rsin, doc_start, dqkv, T, nh, b, h, q0, jt_lo);
-  else attn_bwd_dq_doc_body<NST, false>(smem, qkv, out, dout, lse, ndelta, rcos, rsin, doc_start, dqkv, T, nh, b, h, q0, jt_lo);
-  ATTN_TRACE_T(tr2);
-  ATTN_TRACE_END(1, idx, kc, tr0, tr1, tr2);
+#ifdef PLM_ATTN_TRACE
+  unsigned long long tt[2] = {0, 0};
+#else
+  unsigned long long* tt = nullptr;
+#endif
+  if (kc >> DOC_KIND_SHIFT) attn_bwd_dq_doc_body<NST, true>(smem, qkv, out, dout, lse, ndelta, rcos, rsin, doc_start, dqkv, T, nh, b, h, q0, jt_lo, tt);
+  else attn_bwd_dq_doc_body<NST, false>(smem, qkv, out, dout, lse, ndelta, rcos, rsin, doc_start, dqkv, T, nh, b, h, q0, jt_lo, tt);
+  ATTN_TRACE_END(1, idx, kc, tr0, tt[0], tt[1]);
 }
 
 // =============================================================================================

@@ -66,7 +66,7 @@ def report(name, rec):
     loads[c] = (n + 1, s + int(k), max(last, e))
   per = np.array([v[1] for v in loads.values()])
   cnt = np.array([v[0] for v in loads.values()])
-  if t1.min() > 0 and name.endswith('dK/dV'):
+  if t1.min() > 0:
     early = us(t0) < 2.0
     for tag, m in (('first round', early), ('later rounds', ~early)):
       if m.any():

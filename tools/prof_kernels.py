@@ -120,14 +120,15 @@ def main():
         tot += n
       docs.append(lens)
     ds = doc_start_from_lengths(docs, T).cuda()
+  plan = ops.attn_doc_plan(ds, nh) if ds is not None else None
   torch.cuda.synchronize()
   for _ in range(2):
-    out, lse = ops.attn_fwd(qkv, B, T, nh, ds)
+    out, lse = ops.attn_fwd(qkv, B, T, nh, ds, plan)
   torch.cuda.synchronize()
-  att_fl = 4.0 * B * nh * 64 * T * (T + 1) / 2
+  att_fl = ops.attn_flops(B, T, nh, 64, ds)  # the pairs the mask leaves (causal: T (T + 1) / 2 per head and sequence)
   entry('attn fwd', 'attn_fwd', att_fl, 2.0 * (M * 3 * d + M * d), B=B, T=T, nh=nh)
   for _ in range(2):
-    ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh, ds)
+    ops.attn_bwd(qkv, out, dout, lse, cos, sin, B, T, nh, ds, plan)
   torch.cuda.synchronize()
   for kname in ('attn_bwd_dq', 'attn_bwd_dkdv', 'attn_bwd_fused', 'attn_bwd_dq_reduce'):
     order.append(dict(name=kname, match=kname, flops=2.0 * att_fl if kname in ('attn_bwd_fused',) else att_fl, algorithmic_bytes=2.0 * (M * 3 * d * 2 + M * d * 2),
