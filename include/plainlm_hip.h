@@ -97,6 +97,11 @@ int plm_colsum_f32_multi(const plm_colsum_item* items, int count, int64_t rows, 
  * bwd: du[:, :h] = d/dx, du[:, h:] = d/dz (bf16 autograd chain of the reference) */
 int plm_swiglu_fwd(const uint16_t* u, uint16_t* out, int64_t M, int64_t h, void* stream);
 int plm_swiglu_bwd(const uint16_t* dout, const uint16_t* u, uint16_t* du, int64_t M, int64_t h, void* stream);
+/* The activations of the reference's two plain MLP classes (models/components.py:31-40 `MLP` = fc2(silu(fc1 x)); :59-70 `MLPReluSquared` =
+ * fc2(relu(fc1 x)^2); models/transformer.py:26 MLP_CLASSES), element-wise over n = M * h bf16 values (n % 8 == 0, 16-byte aligned):
+ * kind 0 = silu, 1 = relu squared; fp32 math, bf16 results in the autocast rounding order.  plm_act_bwd: du = dout * act'(u). */
+int plm_act_fwd(const uint16_t* u, uint16_t* out, int64_t n, int kind, void* stream);
+int plm_act_bwd(const uint16_t* dout, const uint16_t* u, uint16_t* du, int64_t n, int kind, void* stream);
 
 /* ---- bf16 MFMA GEMMs (nn.Linear: transformer.py:36-37,42,67,97,114; components.py:50-51)
  * nt: C[M,N] = alpha * A[M,K] · B[N,K]^T        A,B bf16 K-contiguous (y = x W^T, and dX = dY (W^T)^T)

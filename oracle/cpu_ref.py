@@ -48,6 +48,7 @@ class OracleConfig:
   rmsnorm_eps: float = 1e-6
   tie_embeddings: bool = False
   rope_theta: float = 500000.0  # models/transformer.py:99
+  mlp: str = 'glu'              # models/transformer.py:26 MLP_CLASSES: 'glu' (every shipped config) | 'mlp' | 'mlp_relu_sq'
 
   @property
   def head_dim(self) -> int:
@@ -96,7 +97,7 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, tuple]:
     shapes[f'layers.{i}.attn.w_qkv.weight'] = (3 * d, d)
     shapes[f'layers.{i}.attn.w_out.weight'] = (d, d)
     shapes[f'layers.{i}.attn_norm.weight'] = (d,)
-    shapes[f'layers.{i}.mlp.fc1.weight'] = (2 * h, d)
+    shapes[f'layers.{i}.mlp.fc1.weight'] = ((2 * h if cfg.mlp == 'glu' else h), d)  # components.py:50 (GLU: gate | up) vs :35, :65
     shapes[f'layers.{i}.mlp.fc2.weight'] = (d, h)
     shapes[f'layers.{i}.mlp_norm.weight'] = (d,)
   return shapes
@@ -202,6 +203,18 @@ def swiglu(u: Tensor, hidden: int) -> Tensor:
   return torch.nn.functional.silu(x) * z
 
 
+def mlp_act(u: Tensor, hidden: int, kind: str) -> Tensor:
+  """The activation between fc1 and fc2 of the three MLP classes (models/components.py): 'glu' :55-56 silu(x) * z, 'mlp' :40 silu(u),
+  'mlp_relu_sq' :70 relu(u)^2."""
+  if kind == 'glu':
+    return swiglu(u, hidden)
+  if kind == 'mlp':
+    return torch.nn.functional.silu(u)
+  if kind == 'mlp_relu_sq':
+    return torch.relu(u).pow(2)
+  raise ValueError(f'unknown mlp class {kind!r}')
+
+
 def cross_entropy(logits: Tensor, targets: Tensor) -> Tensor:
   """engine/engine.py:81,111: mean over tokens of logsumexp(l) - l[target], fp32."""
   lf = logits.float()
@@ -229,7 +242,7 @@ def forward(params: Dict[str, Tensor], cfg: OracleConfig, ids: Tensor, doc_start
     x = x + a @ params[p + 'attn.w_out.weight'].t()
     n2 = rmsnorm(x, params[p + 'mlp_norm.weight'], cfg.rmsnorm_eps)
     u = n2 @ params[p + 'mlp.fc1.weight'].t()
-    x = x + swiglu(u, h) @ params[p + 'mlp.fc2.weight'].t()
+    x = x + mlp_act(u, h, cfg.mlp) @ params[p + 'mlp.fc2.weight'].t()
   xn = rmsnorm(x, params['out_norm.weight'], cfg.rmsnorm_eps)
   head = params['embed_tokens.weight'] if cfg.tie_embeddings else params['lm_head.weight']
   return xn @ head.t()

@@ -65,6 +65,8 @@ SIGNATURES = {
   'plm_colsum_f32_multi': (_I, [C.POINTER(ColsumItem), _I, _I64, _I64, _P]),
   'plm_swiglu_fwd': (_I, [_P, _P, _I64, _I64, _P]),
   'plm_swiglu_bwd': (_I, [_P, _P, _P, _I64, _I64, _P]),
+  'plm_act_fwd': (_I, [_P, _P, _I64, _I, _P]),
+  'plm_act_bwd': (_I, [_P, _P, _P, _I64, _I, _P]),
   'plm_gemm_bf16_nt': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _P]),
   'plm_gemm_bf16_nt_ex': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I, _I, _P, _I, _P]),
   'plm_gemm_nt_workspace_bytes': (_SZ, [_I64, _I64, _I64]),

@@ -720,6 +720,68 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restr
   st_bf16x8(du + m * 2 * h + h + c, dzo);
 }
 
+// The activations of the reference's two plain MLPs (models/components.py:31-40 `MLP`: fc2(silu(fc1 x)); :59-70 `MLPReluSquared`:
+// fc2(relu(fc1 x)^2)), forward and backward, bf16 in / out with fp32 math and the autocast rounding order (every torch op rounds its bf16
+// result: relu(x)^2 is bf16(r * r) of the bf16 r).  kind 0 = silu, 1 = relu squared.  Same launch shape as the SwiGLU kernels above.
+template <int KIND>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ out, int64_t n8) {
+  const int64_t i = PLM_REV_BLOCK() * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8_t xv = ld_bf16x8(u + i * 8);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float xf = bf2f(xv[e]);
+    if (KIND == 0) o[e] = f2bf(xf * plm_sigmoid(xf));
+    else {
+      const float r = fmaxf(xf, 0.f);
+      o[e] = f2bf(r * r);
+    }
+  }
+  st_bf16x8(out + i * 8, o);
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ u,
+                                                      uint16_t* __restrict__ du, int64_t n8) {
+  const int64_t i = PLM_REV_BLOCK() * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8_t xv = ld_bf16x8(u + i * 8), gv = ld_bf16x8(dout + i * 8);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float xf = bf2f(xv[e]), gf = bf2f(gv[e]);
+    if (KIND == 0) {
+      const float sig = plm_sigmoid(xf);
+      o[e] = f2bf(gf * (sig * (1.f + xf * (1.f - sig))));
+    } else {
+      o[e] = f2bf(bf2f(f2bf(gf * 2.f * fmaxf(xf, 0.f))));  // pow's backward (bf16), then relu's mask (already zero where x <= 0)
+    }
+  }
+  st_bf16x8(du + i * 8, o);
+}
+
+extern "C" int plm_act_fwd(const uint16_t* u, uint16_t* out, int64_t n, int kind, void* stream) {
+  PLM_REQUIRE(u && out && n > 0 && n % 8 == 0 && (kind == 0 || kind == 1), "plm_act_fwd: bad arguments (n %% 8 == 0, kind 0 = silu | 1 = relu^2)");
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "plm_act_fwd: pointers must be 16-byte aligned");
+  const int64_t n8 = n / 8, blocks = plm_cdiv(n8, 256);
+  PLM_REQUIRE(blocks < ((int64_t)1 << 31), "plm_act_fwd: too large for one launch");
+  if (kind == 0) hipLaunchKernelGGL(act_fwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, out, n8);
+  else hipLaunchKernelGGL(act_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, out, n8);
+  PLM_CHECK_LAUNCH("plm_act_fwd");
+  return PLM_OK;
+}
+extern "C" int plm_act_bwd(const uint16_t* dout, const uint16_t* u, uint16_t* du, int64_t n, int kind, void* stream) {
+  PLM_REQUIRE(dout && u && du && n > 0 && n % 8 == 0 && (kind == 0 || kind == 1), "plm_act_bwd: bad arguments (n %% 8 == 0, kind 0 = silu | 1 = relu^2)");
+  PLM_REQUIRE(((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(du)) & 15) == 0,
+              "plm_act_bwd: pointers must be 16-byte aligned");
+  const int64_t n8 = n / 8, blocks = plm_cdiv(n8, 256);
+  PLM_REQUIRE(blocks < ((int64_t)1 << 31), "plm_act_bwd: too large for one launch");
+  if (kind == 0) hipLaunchKernelGGL(act_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, u, du, n8);
+  else hipLaunchKernelGGL(act_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, u, du, n8);
+  PLM_CHECK_LAUNCH("plm_act_bwd");
+  return PLM_OK;
+}
+
 // One item per thread, blocks in memory order: a grid capped at 8192 blocks with a grid-stride loop (every resident block
 // a stride apart) measured 4-5 % slower on the SwiGLU kernels and 29 % slower on AdamW (0.95 -> 0.74 ms for 162M parameters)
 // than letting the dispatcher walk memory linearly (run 32); the stride loop only remains for > 2^20 blocks.

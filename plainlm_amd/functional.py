@@ -191,6 +191,46 @@ class SwiGLUMLPFn(torch.autograd.Function):
     return dx, dw1, dw2, None, None
 
 
+class PlainMLPFn(torch.autograd.Function):
+  """y = fc2(act(fc1 x)) for the reference's plain MLP classes (components.py:31-40 `MLP`: silu; :59-70 `MLPReluSquared`: relu squared)
+  as one autograd node: two NT GEMMs around a stand-alone activation kernel (these classes are off every shipped config's path, so no
+  fused epilogue is built for them), backward = dX of fc2 -> activation backward -> the plain Linear backward of fc1."""
+
+  @staticmethod
+  def forward(ctx, x, w1, w2, fc1, fc2, kind):
+    w1b, _ = fc1.shadow()
+    w2b, _ = fc2.shadow()
+    u = ops.gemm_nt(x, w1b)
+    act = ops.act_fwd(u, kind)
+    ctx.save_for_backward(x, u, act)
+    ctx.fc1, ctx.fc2, ctx.kind = fc1, fc2, kind
+    return ops.gemm_nt(act, w2b)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, u, act = ctx.saved_tensors
+    fc1, fc2 = ctx.fc1, ctx.fc2
+    dy = dy.contiguous()
+    _, w1t = fc1.shadow()
+    _, w2t = fc2.shadow()
+    du = ops.act_bwd(ops.gemm_nt(dy, w2t[:, :fc2.out_features]), u, ctx.kind)
+    dw2 = dw1 = None
+    if ctx.needs_input_grad[2]:
+      sink, p = fc2.sink, fc2.weight
+      if sink is not None and sink.active_for(p):
+        sink.defer_dw(dy, act, p)
+      else:
+        dw2 = ops.gemm_tn(dy, act)
+    dx = ops.gemm_nt(du, w1t[:, :fc1.out_features]) if ctx.needs_input_grad[0] else None
+    if ctx.needs_input_grad[1]:
+      sink, p = fc1.sink, fc1.weight
+      if sink is not None and sink.active_for(p):
+        sink.defer_dw(du, x, p)
+      else:
+        dw1 = ops.gemm_tn(du, x)
+    return dx, dw1, dw2, None, None, None
+
+
 class QKVRopeFn(torch.autograd.Function):
   """w_qkv projection + RoPE (transformer.py:42-47): returns the projection with q | k ALREADY rotated.
   Contract with AttnFn: AttnFn.backward returns the gradient w.r.t. the UN-rotated projection (the inverse

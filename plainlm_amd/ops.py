@@ -230,6 +230,25 @@ def swiglu_bwd(dout, u):
   return du
 
 
+ACT_KINDS = {'silu': 0, 'relu_sq': 1}
+
+
+def act_fwd(u, kind):
+  """bf16 act(u) for the plain MLP classes (components.py:31-40 silu, :59-70 relu squared)."""
+  _need(u, BF16, 'act_fwd.u', 2)
+  out = torch.empty_like(u)
+  _lib.check(_lib.load().plm_act_fwd(_p(u), _p(out), u.numel(), ACT_KINDS[kind], _stream()), 'plm_act_fwd')
+  return out
+
+
+def act_bwd(dout, u, kind):
+  _need(dout, BF16, 'act_bwd.dout', 2)
+  _need(u, BF16, 'act_bwd.u', 2)
+  du = torch.empty_like(u)
+  _lib.check(_lib.load().plm_act_bwd(_p(dout), _p(u), _p(du), u.numel(), ACT_KINDS[kind], _stream()), 'plm_act_bwd')
+  return du
+
+
 # ---- GEMMs ------------------------------------------------------------------------
 _tn_ws = {}
 _nt_ws_cache = {}

@@ -136,13 +136,38 @@ class GLU(nn.Module):
     self.fc1 = HipLinear(dim, 2 * hidden_dim)
     self.fc2 = HipLinear(hidden_dim, dim)
 
+  def apply_fn(self, x2d):
+    return Fn.SwiGLUMLPFn.apply(x2d, self.fc1.weight, self.fc2.weight, self.fc1, self.fc2)
+
   def forward(self, x):
     lead = x.shape[:-1]
-    y = Fn.SwiGLUMLPFn.apply(x.reshape(-1, x.shape[-1]), self.fc1.weight, self.fc2.weight, self.fc1, self.fc2)
-    return y.view(*lead, -1)
+    return self.apply_fn(x.reshape(-1, x.shape[-1])).view(*lead, -1)
 
 
-MLP_CLASSES = {'glu': GLU}
+class MLP(nn.Module):
+  """models/components.py:31-40 (`MLP`: fc2(silu(fc1 x))) and :59-70 (`MLPReluSquared`: fc2(relu(fc1 x)^2)): fc1 [h, d], fc2 [d, h]."""
+  kind = 'silu'
+
+  def __init__(self, dim, hidden_dim, multiple_of=256):
+    super().__init__()
+    hidden_dim = multiple_of * ((hidden_dim + multiple_of - 1) // multiple_of)
+    self.hidden_dim = hidden_dim
+    self.fc1 = HipLinear(dim, hidden_dim)
+    self.fc2 = HipLinear(hidden_dim, dim)
+
+  def apply_fn(self, x2d):
+    return Fn.PlainMLPFn.apply(x2d, self.fc1.weight, self.fc2.weight, self.fc1, self.fc2, self.kind)
+
+  def forward(self, x):
+    lead = x.shape[:-1]
+    return self.apply_fn(x.reshape(-1, x.shape[-1])).view(*lead, -1)
+
+
+class MLPReluSquared(MLP):
+  kind = 'relu_sq'
+
+
+MLP_CLASSES = {'mlp': MLP, 'glu': GLU, 'mlp_relu_sq': MLPReluSquared}  # models/transformer.py:26
 
 
 class Attention(nn.Module):
@@ -166,7 +191,7 @@ class Block(nn.Module):
   def __init__(self, layer_id, cfg):
     super().__init__()
     if cfg.mlp not in MLP_CLASSES:
-      raise NotImplementedError(f"mlp class '{cfg.mlp}' is outside the accelerated hot path (only 'glu' is built)")
+      raise NotImplementedError(f"mlp class '{cfg.mlp}': expected one of {sorted(MLP_CLASSES)} (models/transformer.py:26)")
     self.attn = Attention(cfg)
     self.attn_norm = RMSNorm(cfg.dim, cfg.rmsnorm_eps)
     self.mlp = MLP_CLASSES[cfg.mlp](dim=cfg.dim, hidden_dim=int(cfg.expand * cfg.dim))
@@ -182,7 +207,7 @@ class Block(nn.Module):
       x, n1 = Fn.AddNormFn.apply(x, branch, self.attn_norm.weight, self.attn_norm)
     a = self.attn(n1, rope, doc_start, B, T)
     x, n2 = Fn.AddNormFn.apply(x, a, self.mlp_norm.weight, self.mlp_norm)
-    return x, Fn.SwiGLUMLPFn.apply(n2, self.mlp.fc1.weight, self.mlp.fc2.weight, self.mlp.fc1, self.mlp.fc2)
+    return x, self.mlp.apply_fn(n2)
 
 
 class Transformer(nn.Module):

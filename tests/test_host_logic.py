@@ -83,7 +83,10 @@ def test_unsupported_configs_fail_loudly():
   with pytest.raises(NotImplementedError):
     P.construct_model(_cfg(model='pythia-160m'))
   with pytest.raises(NotImplementedError):
-    P.construct_model(_cfg(mlp_class='mlp'))
+    P.construct_model(_cfg(mlp_class='moe'))
+  for kind in ('mlp', 'mlp_relu_sq'):  # the reference's other two MLP classes are built (models/transformer.py:26): one fc1 projection of h rows
+    m, _ = P.construct_model(_cfg(mlp_class=kind))
+    assert tuple(m.layers[0].mlp.fc1.weight.shape) == (512, 128) and tuple(m.layers[0].mlp.fc2.weight.shape) == (128, 512)
   with pytest.raises(NotImplementedError):
     P.construct_model(_cfg(n_heads=4))  # head_dim 32
   with pytest.raises(ValueError):

@@ -264,6 +264,35 @@ def test_engine_loss_sequence_vs_reference(P, mdl, golden_dir):
   print(f'final parameters vs bf16-emulating oracle: max |diff| = {worst / 3e-3:.2f} lr')
 
 
+@pytest.mark.parametrize('kind', ['mlp', 'mlp_relu_sq'])
+def test_plain_mlp_classes_vs_reference(P, golden_dir, kind):
+  """The reference's other two MLP classes (models/transformer.py:26; components.py:31-40 silu MLP, :59-70 relu-squared MLP) on the HIP path
+  (two NT GEMMs around plm_act_fwd / plm_act_bwd): loss within 1e-4, logits and all 15 gradients against the REFERENCE model's own
+  outputs (tests/golden/make_mlp_classes.py); also through the flat-gradient path the engine uses."""
+  z = np.load(os.path.join(golden_dir, 'mlp_classes.npz'))
+  ocfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2, mlp=kind)
+  w = O.init_params(ocfg, seed=3)
+  tok = torch.from_numpy(z['tokens'])
+  ids, tgt = tok[:, :64].cuda(), tok[:, 1:].contiguous().cuda()
+  for main_grad in (False, True):
+    m = P.Transformer(P.ModelConfig(vocab_size=256, seq_len=64, dim=128, expand=8 / 3, n_layers=2, n_heads=2, mlp=kind))
+    m.load_state_dict(w)
+    m = m.cuda()
+    if main_grad:
+      m.enable_main_grad()
+      m.sink.begin_window()
+    logits = m(ids, None)
+    assert relmax(logits.float().cpu(), torch.from_numpy(z[f'{kind}:logits'])) < 2e-2
+    loss = m.loss(ids, tgt)
+    loss.backward()
+    if main_grad:
+      m.attach_grads()
+    ref = float(z[f'{kind}:loss'])
+    assert abs(loss.item() - ref) <= LOSS_RTOL * abs(ref), (loss.item(), ref)
+    worst = {n: relmax(p.grad.float().cpu(), torch.from_numpy(z[f'{kind}:g:{n}'])) for n, p in m.named_parameters()}
+    assert len(worst) == 15 and max(worst.values()) < 4e-2, worst
+
+
 def test_engine_cfg1_literal_shape_vs_reference(P, golden_dir):
   """BASELINE configs[0] at its literal shape through HipEngine on the GPU: 2 layers, d = 128, 2 heads, seq 128, the REAL vocabulary
   (50 280: with d = 128 the ragged lm_head and its gradient GEMMs take the small-shape kernels no other model-level test reaches),

@@ -200,6 +200,23 @@ def test_engine_cfg1_literal_shape(golden_dir):
   _close(eng.params['out_norm.weight'], z['final:out_norm.weight'], 5e-6)
 
 
+@pytest.mark.parametrize('kind', ['mlp', 'mlp_relu_sq'])
+def test_plain_mlp_classes_vs_reference(golden_dir, kind):
+  """models/transformer.py:26: the two MLP classes beside 'glu' (components.py:31-40 silu MLP, :59-70 relu-squared MLP) - loss, logits and all
+  15 gradients of the reference model on the CPU (tests/golden/make_mlp_classes.py)."""
+  z = _load(golden_dir, 'mlp_classes.npz')
+  cfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2, mlp=kind)
+  assert O.param_shapes(cfg)['layers.0.mlp.fc1.weight'] == (512, 128)  # one projection, not gate | up
+  w = O.init_params(cfg, seed=3)
+  np.testing.assert_allclose(_cfg1_checksums(w), z[f'{kind}:init_checksums'].numpy(), rtol=1e-12)
+  tok = z['tokens']
+  _close(O.forward(w, cfg, tok[:, :64]), z[f'{kind}:logits'], 5e-6)
+  loss, g = O.loss_and_grads(w, cfg, tok[:, :64], tok[:, 1:])
+  _close(loss, z[f'{kind}:loss'])
+  for n in w:
+    _close(g[n], z[f'{kind}:g:{n}'], 5e-6)
+
+
 # ---- bf16-emulating mode (oracle/cpu_ref_bf16.py) ----------------------------------------------------------------------
 def test_bf16_mode_without_rounding_equals_fp32_oracle(mdl):
   """The hand-written forward + backward of the emulating mode IS the reference's algorithm: with the bf16 rounding
