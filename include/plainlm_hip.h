@@ -197,6 +197,11 @@ int plm_fc2_dx_swiglu_bwd_bf16(const uint16_t* dY, int64_t lddy, const uint16_t*
  * plan is caller-owned device memory of plm_attn_doc_plan_bytes(B, T) bytes, 16-byte aligned; doc_start must be non-decreasing along T with
  * doc_start[b][i] <= i.  plm_attn_fwd / plm_attn_bwd: doc_start == NULL -> causal (doc_plan ignored); otherwise doc_plan is required
  * (PLM_E_INVALID without it). */
+/* The reference's own mask format -> doc_start: mask is the bool [B, T, T] tensor of engine/engine.py:21-23 (one byte per element, nonzero =
+ * may attend), doc_start[b][i] = first allowed key of row i.  Every row is checked to be exactly [doc_start, i] (the block-diagonal causal
+ * masks of data_prep_utils.py:7-23 are); status[0] (caller-zeroed int32) is set to 1 when some row is not - such a mask cannot be expressed
+ * as doc_start and the caller must refuse it. */
+int plm_attn_doc_start_from_mask(const uint8_t* mask, int32_t* doc_start, int32_t* status, int64_t B, int64_t T, void* stream);
 int64_t plm_attn_doc_plan_bytes(int64_t B, int64_t T);
 int plm_attn_doc_plan(const int32_t* doc_start, int32_t* plan, int64_t B, int64_t T, int64_t nh, void* stream);
 int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, const int32_t* doc_plan, uint16_t* out, float* lse, int64_t B, int64_t T,

@@ -79,6 +79,7 @@ SIGNATURES = {
   'plm_qkv_rope_bf16': (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
   'plm_fc1_swiglu_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P]),
   'plm_fc2_dx_swiglu_bwd_bf16': (_I, [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _P]),
+  'plm_attn_doc_start_from_mask': (_I, [_P, _P, _P, _I64, _I64, _P]),
   'plm_attn_doc_plan_bytes': (_I64, [_I64, _I64]),
   'plm_attn_doc_plan': (_I, [_P, _P, _I64, _I64, _I64, _P]),
   'plm_attn_fwd': (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),

@@ -46,6 +46,7 @@ void plm_attn_bwd_causal(const uint16_t* qkv, const uint16_t* out, const uint16_
                          const float* rs, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, hipStream_t s);
 // document masks: attn_doc.hip
 void plm_attn_doc_plan_launch(const int32_t* doc_start, int32_t* plan, int64_t B, int64_t T, int64_t nh, int split_min_q, hipStream_t s);
+void plm_attn_doc_start_from_mask_launch(const uint8_t* mask, int32_t* doc_start, int32_t* status, int64_t B, int64_t T, hipStream_t s);
 void plm_attn_fwd_doc(const uint16_t* qkv, const int32_t* doc_start, const int32_t* plan, uint16_t* out, float* lse, int64_t B, int64_t T,
                       int64_t nh, hipStream_t s);
 void plm_attn_bwd_doc(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta, const float* rc,
@@ -80,6 +81,16 @@ extern "C" int plm_attn_doc_plan(const int32_t* doc_start, int32_t* plan, int64_
   if (int rc = check_attn_shape("plm_attn_doc_plan", B, T, nh, HD)) return rc;
   plm_attn_doc_plan_launch(doc_start, plan, B, T, nh, plm_env().attn_doc_split_min, (hipStream_t)stream);
   PLM_CHECK_LAUNCH("plm_attn_doc_plan");
+  return PLM_OK;
+}
+
+extern "C" int plm_attn_doc_start_from_mask(const uint8_t* mask, int32_t* doc_start, int32_t* status, int64_t B, int64_t T, void* stream) {
+  PLM_REQUIRE(mask && doc_start && status, "plm_attn_doc_start_from_mask: null pointer");
+  PLM_REQUIRE((reinterpret_cast<uintptr_t>(mask) & 3) == 0, "plm_attn_doc_start_from_mask: mask must be 4-byte aligned");
+  if (int rc = check_attn_shape("plm_attn_doc_start_from_mask", B, T, 1, HD)) return rc;
+  PLM_REQUIRE(B * T < ((int64_t)1 << 31), "plm_attn_doc_start_from_mask: B x T too large");
+  plm_attn_doc_start_from_mask_launch(mask, doc_start, status, B, T, (hipStream_t)stream);
+  PLM_CHECK_LAUNCH("plm_attn_doc_start_from_mask");
   return PLM_OK;
 }
 

@@ -139,6 +139,41 @@ __global__ __launch_bounds__(1024) void attn_doc_plan_kernel(const int32_t* __re
 }
 
 // =============================================================================================
+// The reference's own calling convention: a bool [B, T, T] mask (True = may attend; data_prep_utils.py:7-23 stacked at engine/engine.py:21-23).
+// One wave per query row: doc_start = the row's first True, and the row is CHECKED to be exactly True on [doc_start, i] - the only masks
+// doc_start[B, T] can express; any other row raises status[0] (the caller reports it: a mask that is silently mis-read would train on the
+// wrong attention pattern).  Replaces an aten cast + argmax over B T^2 elements.
+// =============================================================================================
+__global__ __launch_bounds__(256) void doc_start_from_mask_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ doc_start,
+                                                                  int32_t* __restrict__ status, int64_t rows, int T) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int i = (int)(row % T);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(mask + row * T);  // T % 4 == 0: every row starts on a word
+  const int nw = T >> 2;
+  int first = T;
+  for (int k = lane; k < nw; k += 64) {
+    const uint32_t v = w[k];
+    if (v && first == T) first = 4 * k + (__builtin_ctz(v) >> 3);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+  bool bad = first > i;  // a query sees at least itself
+  const int ds = bad ? i : first;
+  for (int k = lane; k < nw; k += 64) {
+    const uint32_t v = w[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * k + e;
+      bad |= (((v >> (8 * e)) & 0xffu) != 0u) != (j >= ds && j <= i);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicOr(status, 1);
+  if (lane == 0) doc_start[row] = ds;
+}
+
+// =============================================================================================
 // forward.  A 128-row item (SPLIT = false): 4 waves x 32 query rows; a 64-row item (SPLIT = true): wave = (row block rb = wave & 1, part = wave >> 1),
 // the two parts of a row block take the two 32-key halves of every tile and merge their (reference maximum, sum, O) once, at the end, through LDS.
 // K | V tiles of 64 keys go through an NST-deep LDS ring filled NST - 1 tiles ahead (counted vmcnt waits, one barrier per tile).
@@ -581,6 +616,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_doc_kernel(const uint16_t*
 void plm_attn_bwd_dkdv_doc(const uint16_t* qkv, const uint16_t* dout, const float* lse, const float* ndelta, const float* rc, const float* rs,
                            const int32_t* header, const int32_t* doc_end, const int4* items_k, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh,
                            hipStream_t s);
+
+void plm_attn_doc_start_from_mask_launch(const uint8_t* mask, int32_t* doc_start, int32_t* status, int64_t B, int64_t T, hipStream_t s) {
+  const int64_t rows = B * T;
+  hipLaunchKernelGGL(doc_start_from_mask_kernel, dim3((unsigned)plm_cdiv(rows, 4)), dim3(256), 0, s, mask, doc_start, status, rows, (int)T);
+}
 
 void plm_attn_doc_plan_launch(const int32_t* doc_start, int32_t* plan, int64_t B, int64_t T, int64_t nh, int split_min_q, hipStream_t s) {
   const unsigned blocks = (unsigned)plm_cdiv(B * T, 1024) + 1;  // doc_end[] blocks + the one block that builds and sorts the item lists

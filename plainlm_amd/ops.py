@@ -463,6 +463,19 @@ def qkv_rope(x, w_qkv, rope_cos, rope_sin, B, T, nh):
   return out
 
 
+def doc_start_from_mask(mask):
+  """bool [B, T, T] (True = may attend: the reference's mask, engine/engine.py:21-23) -> (doc_start int32 [B, T], status int32 [1]): status
+  becomes 1 when some row is not exactly True on [doc_start, i] - the caller decides when to look (it is a device tensor)."""
+  if mask.dtype != torch.bool or mask.dim() != 3 or mask.shape[1] != mask.shape[2] or not mask.is_cuda:
+    raise ValueError('doc_start_from_mask: need a bool [B, T, T] tensor on the GPU')
+  mask = mask.contiguous()
+  B, T = mask.shape[0], mask.shape[1]
+  ds = torch.empty((B, T), dtype=torch.int32, device=mask.device)
+  status = torch.zeros((1,), dtype=torch.int32, device=mask.device)
+  _lib.check(_lib.load().plm_attn_doc_start_from_mask(_p(mask), _p(ds), _p(status), B, T, _stream()), 'plm_attn_doc_start_from_mask')
+  return ds, status
+
+
 def attn_doc_plan(doc_start, nh):
   """Plan of a document-masked batch for attention with nh heads (include/plainlm_hip.h: doc_end[B,T] + the sorted item lists): built ONCE
   per batch, shared by every layer's forward / backward launches."""

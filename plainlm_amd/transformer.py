@@ -341,18 +341,36 @@ class Transformer(nn.Module):
       self._rope_dev = tuple(t.to(device) for t in self._rope_host)
     return self._rope_dev
 
-  @staticmethod
-  def _doc_start(attn_mask, B, T):
+  _mask_status = None  # device flag of the LAST bool-mask conversion (checked one call later: reading it at once would wait for the GPU)
+
+  @classmethod
+  def _doc_start(cls, attn_mask, B, T):
     if attn_mask is None:
       return None
+    if isinstance(attn_mask, Fn.DocMask):
+      return attn_mask
     if attn_mask.dim() == 2 and attn_mask.dtype in (torch.int32, torch.int64):
       return attn_mask.to(torch.int32).contiguous()
     if attn_mask.dim() == 3 and attn_mask.dtype == torch.bool:
-      # block-diagonal causal mask of data_prep_utils.py:7-23: first allowed key of every query row
+      # block-diagonal causal mask of data_prep_utils.py:7-23 (the reference's calling convention, engine/engine.py:21-23,109): first allowed
+      # key of every query row, by one small kernel that also CHECKS every row to be exactly [first, i]
       if attn_mask.shape != (B, T, T):
         raise ValueError(f'attn_mask must be [B,T,T]={B, T, T}, got {tuple(attn_mask.shape)}')
-      return attn_mask.to(torch.uint8).argmax(dim=-1).to(torch.int32).contiguous()
+      if not attn_mask.is_cuda:  # host logic / CPU tests: the same definition with torch ops
+        return attn_mask.to(torch.uint8).argmax(dim=-1).to(torch.int32).contiguous()
+      cls.check_mask_status()
+      ds, cls._mask_status = ops.doc_start_from_mask(attn_mask)
+      return ds
     raise TypeError('attn_mask must be None, a bool [B,T,T] mask or an int32 doc_start [B,T]')
+
+  @classmethod
+  def check_mask_status(cls):
+    """Raises if the previous bool mask was not a block-diagonal causal mask (rows exactly True on [doc_start, i]): any other mask cannot
+    be expressed as doc_start and would have been mis-read.  Called at the next conversion (and by the tests); the flag has long been written."""
+    st, cls._mask_status = cls._mask_status, None
+    if st is not None and int(st.item()) != 0:
+      raise ValueError('attn_mask: a row of the previous bool mask was not exactly True on [first allowed key, query]: only block-diagonal causal '
+                       'masks (data_prep_utils.py:7-23) are supported')
 
   def _trunk(self, x, attn_mask):
     if x.dim() != 2 or x.dtype != torch.int64:
@@ -364,7 +382,7 @@ class Transformer(nn.Module):
       raise ValueError(f'sequence length {T} exceeds cfg.seq_len {self.cfg.seq_len}')
     rope = self._rope(x.device)
     doc_start = self._doc_start(attn_mask, B, T)
-    if doc_start is not None:
+    if doc_start is not None and not isinstance(doc_start, Fn.DocMask):
       doc_start = Fn.DocMask(doc_start, self.cfg.n_heads)  # + the plan: one small launch per batch, shared by every layer's attention launches
     self.refresh_shadows()
     h = self.embed_tokens(x).view(B * T, self.cfg.dim)

@@ -702,6 +702,41 @@ def test_attention_doc_mask_structures(ops, kind):
     close(out.float(), outc.float(), 8e-3, 'one document per row vs the causal kernels')
 
 
+@pytest.mark.parametrize('B,T', [(2, 64), (3, 200), (4, 1024)])
+def test_doc_start_from_the_references_bool_mask(ops, B, T):
+  """The reference passes a bool [B, T, T] mask (engine/engine.py:21-23, data_prep_utils.py:7-23); plm_attn_doc_start_from_mask turns it into
+  doc_start and CHECKS every row: a block-diagonal causal mask converts exactly (status 0), a mask doc_start cannot express (a hole inside a
+  document, a key ahead of the query, an empty row) raises the status flag."""
+  ds = O.doc_start_from_lengths(_random_docs(B, T, 11 * T + B), T)
+  mask = O.mask_from_doc_start(ds)
+  got, status = ops.doc_start_from_mask(mask.cuda())
+  assert torch.equal(got.cpu(), ds) and status.item() == 0
+  bi = [(b, i) for b in range(B) for i in range(T) if int(ds[b, i]) <= i - 2]  # rows that see at least three keys
+  for what in ('hole', 'future', 'empty'):
+    bad = mask.clone()
+    b, i = bi[len(bi) // 2]
+    if what == 'hole':
+      bad[b, i, i - 1] = False  # a key inside the row's document is missing
+    elif what == 'future':
+      bad[b, i, min(i + 4, T - 1)] = True if i + 1 < T else bad[b, i, T - 1]
+      if i + 1 >= T:
+        bad[b, i - 1, i] = True
+    else:
+      bad[b, i, :] = False
+    _, status = ops.doc_start_from_mask(bad.cuda())
+    assert status.item() == 1, what
+  # through the model API: Transformer._doc_start refuses such a mask at the next conversion
+  import plainlm_amd as P
+  P.Transformer._mask_status = None
+  bad = mask.clone()
+  bad[0, 5, 9] = True
+  P.Transformer._doc_start(bad.cuda(), B, T)
+  with pytest.raises(ValueError, match='block-diagonal'):
+    P.Transformer._doc_start(mask.cuda(), B, T)
+  assert torch.equal(P.Transformer._doc_start(mask.cuda(), B, T).cpu(), ds)
+  P.Transformer.check_mask_status()
+
+
 def test_attention_doc_requires_plan_at_the_c_abi(ops):
   """The C entry points refuse a document mask without its plan (no silent slow path)."""
   import ctypes as C
