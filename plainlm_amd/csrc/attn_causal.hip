@@ -514,22 +514,41 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(char* smem, const uint16_t* _
   };
   // the first Q | dO tiles are on their way before the wave's K / V rows are asked for (the two latencies overlap; the ordinary loads are
   // younger than the DMA, so waiting for them covers it)
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)
-    if (i < n) stage(i, jq_lo + i);
-
   bf16x8_t kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
-    kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
-    vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
-  }
   int de = T;  // first query that does not see this lane's key
-  if (DOC) de = doc_end[(int64_t)b * T + min(kvrow, T - 1)];
-  asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]),
-               "v"(vf[3]), "v"(de));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed: nothing but LDS-DMA is counted from here on
+  if (DOC) {
+    // document masks (small grids, every workgroup starts in the same microsecond): the wave's K and V rows come by LDS-DMA into its quarters
+    // of slots 1 and 2 (whole 128-byte rows: rows_dma, attn_common.h) instead of 32-byte fragment loads; tile 1 is staged when every wave
+    // has its fragments (the barrier below), tile 2 at the loop's first step as always.  Rows beyond T repeat row T - 1 (never stored).
+    static_assert(!DOC || NST == 3, "the prologue parks the wave's rows in slots 1 and 2");
+    if (n > 0) stage(0, jq_lo);
+    char* kreg = smem + 1 * STAGE + wave * 4096;
+    char* vreg = smem + 2 * STAGE + wave * 4096;
+    rows_dma(kreg, base + dm, ld, kvw0, T - 1, lane);
+    rows_dma(vreg, base + 2 * dm, ld, kvw0, T - 1, lane);
+    de = doc_end[(int64_t)b * T + min(kvrow, T - 1)];
+    asm volatile("; row data requested" ::"v"(de));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows and tile 0 have landed: nothing but LDS-DMA is counted from here on
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = rows_frag(kreg, l31, ks, hi);
+      vf[ks] = rows_frag(vreg, l31, ks, hi);
+    }
+    attn_barrier();
+    if (n > 1) stage(1, jq_lo + 1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < n) stage(i, jq_lo + i);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint16_t* p = base + (int64_t)kvrow * ld + ks * 16 + hi * 8;
+      kf[ks] = kvalid ? ld_bf16x8(p + dm) : zero_bf16x8();
+      vf[ks] = kvalid ? ld_bf16x8(p + 2 * dm) : zero_bf16x8();
+    }
+    asm volatile("; k/v fragments resident" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed: nothing but LDS-DMA is counted from here on
+  }
   const int de_lo = DOC ? __builtin_amdgcn_readlane(de, 0) : T, de_hi = DOC ? __builtin_amdgcn_readlane(de, 31) : T;  // the wave's first / last key
 
   f32x16_t dk[2], dv[2];

@@ -258,6 +258,20 @@ def _lib_ws(M, N, K):
   return _lib.load().plm_gemm_nt_workspace_bytes(M, N, K)
 
 
+def host_rows(out, A, B, tol, what, tn=False, n_rows=48):
+  """A slice of the result against the HOST's fp32 arithmetic (the full-size references of these tests come from the same device's fp32
+  matmul - an independent implementation, but not the CPU): 48 output rows spread over the whole matrix, first and last included -
+  rows of A B^T (NT), columns of A as rows of A^T B (TN) - recomputed on the CPU in fp64."""
+  M = out.shape[0]
+  rows = torch.unique(torch.cat([torch.tensor([0, M - 1]), torch.linspace(0, M - 1, n_rows).long(),
+                                 torch.randint(0, M, (8,), generator=torch.Generator().manual_seed(M))]))
+  Ah, Bh = A.cpu().double(), B.cpu().double()
+  ref = (Ah[:, rows].t() @ Bh) if tn else (Ah[rows] @ Bh.t())
+  got = out[rows.to(out.device)].double().cpu()
+  e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+  assert e <= tol, f'{what} vs host fp64 on {len(rows)} rows: rel-to-max error {e:.3e} > {tol:.1e}'
+
+
 @pytest.mark.parametrize('M,N,K', NT_SHAPES + NT_SHAPES_420M)
 def test_gemm_nt(ops, M, N, K):
   g = torch.Generator().manual_seed(M + N + K)
@@ -266,6 +280,7 @@ def test_gemm_nt(ops, M, N, K):
   ref = A.float() @ B.float().t()
   out32 = ops.gemm_nt(A, B, out_dtype=torch.float32)
   close(out32, ref, 2e-5 * math.sqrt(K), f'gemm_nt fp32 {M}x{N}x{K}')
+  host_rows(out32, A, B, 2e-5 * math.sqrt(K), f'gemm_nt fp32 {M}x{N}x{K}')
   out16 = ops.gemm_nt(A, B)
   close(out16.float(), ref, 6e-3, f'gemm_nt bf16 {M}x{N}x{K}')
   # accumulate + device alpha
@@ -287,6 +302,7 @@ def test_gemm_nt_variants(ops, M, N, K, variant):
   ref = A.float() @ B.float().t()
   out = ops.gemm_nt(A, B, variant=variant)
   close(out.float(), ref, 6e-3, f'gemm_nt variant {variant} {M}x{N}x{K}')
+  host_rows(out, A, B, 6e-3, f'gemm_nt variant {variant} {M}x{N}x{K}')
   alpha = torch.tensor(-0.5, device='cuda')
   wide = torch.zeros(M, N + 24, dtype=torch.bfloat16, device='cuda')  # padded rows (ldc > N)
   ops.gemm_nt(A, B, out=wide[:, :N], alpha=alpha, variant=variant)
@@ -384,6 +400,7 @@ def test_gemm_tn(ops, M, N, K):
   ref = A.float().t() @ B.float()
   out = ops.gemm_tn(A, B)
   close(out, ref, 2e-5 * math.sqrt(K), f'gemm_tn {M}x{N}x{K}')
+  host_rows(out, A, B, 2e-5 * math.sqrt(K), f'gemm_tn {M}x{N}x{K}', tn=True)
   acc = torch.full((M, N), 2.0, device='cuda')
   alpha = torch.tensor(0.25, device='cuda')
   ops.gemm_tn(A, B, out=acc, accumulate=True, alpha=alpha)
