@@ -90,28 +90,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t*
   const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
   const float c2 = 0.125f * LOG2E;  // 1/sqrt(64) and the base-2 exponent in one factor
 
-  bf16x8_t qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = r0[qb] + l31;
-    const bool qvalid = qrow < T;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
-  }
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-    asm volatile("; q fragments resident" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]));  // consumed before any DMA is in flight
-
-  f32x16_t o[2][2];
-  float mc[2], lsum[2];  // running reference maximum in log2 units (s * c2), running sum
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    zero16(o[qb][0]);
-    zero16(o[qb][1]);
-    mc[qb] = -INFINITY;
-    lsum[qb] = 0.f;
-  }
-
   const int kv_hi = min(T, q0 + QB);
   const int jt_hi = (kv_hi + KT - 1) / KT;
   constexpr int jt_lo = 0;
@@ -130,6 +108,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t*
       dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
     }
   };
+
+  // ring: tile i = jt - jt_lo lives in slot i % NST; tiles are issued NST - 1 ahead.  Tile 0 goes out BEFORE the Q rows are asked for (round 6:
+  // the two latencies overlap; the ordinary loads are younger than the DMA, so waiting for them covers it), the others right behind them
+  if (n > 0) stage(0, jt_lo);
+
+  bf16x8_t qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = r0[qb] + l31;
+    const bool qvalid = qrow < T;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = qvalid ? ld_bf16x8(base + (int64_t)qrow * ld + ks * 16 + hi * 8) : zero_bf16x8();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) asm volatile("; q fragments resident" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed (and tile 0 with them): nothing but LDS-DMA is counted from here on
+#pragma unroll
+  for (int i = 1; i < NST - 1; ++i)
+    if (i < n) stage(i, jt_lo + i);
+
+  f32x16_t o[2][2];
+  float mc[2], lsum[2];  // running reference maximum in log2 units (s * c2), running sum
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    zero16(o[qb][0]);
+    zero16(o[qb][1]);
+    mc[qb] = -INFINITY;
+    lsum[qb] = 0.f;
+  }
 
   // one row block's softmax + P V for one tile (s: its S^T accumulators, vfr: the tile's V fragments)
   auto soft_pv = [&](int qb_, f32x16_t (&s)[2], const bf16x8_t (&vfr)[2][4], int kv0, auto mask_tag) {
@@ -214,10 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_causal_kernel(const uint16_t*
     if (M1 == QB_MASK) soft_pv(1, s[1], vfr, kv0, std::true_type{});
   };
 
-  // ring: tile i = jt - jt_lo lives in slot i % NST; tiles are issued NST - 1 ahead
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)
-    if (i < n) stage(i, jt_lo + i);
+  // (tile 0 was issued in front of the Q loads, the others behind them)
   int i = 0, slot = 0;
   auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
     for (; jt_lo + i < jt_end; ++i) {
@@ -294,6 +298,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
   const uint16_t* base = qkv + (int64_t)b * T * ld + h * HD;
   const float scale = 0.125f, c2 = scale * LOG2E;
 
+  const int kv_hi = min(T, q0 + QB);
+  const int jt_hi = (kv_hi + KT - 1) / KT;
+  constexpr int jt_lo = 0;
+  const int n = jt_hi;
+
+  TileDma dma;
+  dma.init(wave, lane, ld);
+  auto stage = [&](int slot, int jt) {  // 4 LDS-DMA instructions per wave
+    const int kv0 = jt * KT;
+    const uint16_t* src = base + (int64_t)kv0 * ld;
+    if (kv0 + KT <= T) {
+      dma.issue_full(smem + slot * 2 * TILE, src + dm, wave);
+      dma.issue_full(smem + slot * 2 * TILE + TILE, src + 2 * dm, wave);
+    } else {
+      dma.issue(smem + slot * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
+      dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
+    }
+  };
+
+  if (n > 0) stage(0, jt_lo);  // in front of the row loads: the two latencies overlap (see the forward kernel)
+
   bf16x8_t qf[2][4], dof[2][4];
   float Lq[2], Dq[2];
 #pragma unroll
@@ -319,14 +344,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
     }
     float d_lo, d_hi;
     half_pair(part, d_lo, d_hi);  // rows beyond T hold zeros in both halves
-    Dq[qb] = d_lo + d_hi;
-    if (qvalid && hi == 0) delta[((int64_t)b * nh + h) * T + qrow] = Dq[qb] * dsign;
+    Dq[qb] = d_lo + d_hi;         // published in the epilogue (round 6): a store here had to be waited for before the counted DMA waits could start
   }
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
     asm volatile("; q/dO fragments resident" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]), "v"(dof[qb][0]), "v"(dof[qb][1]),
                  "v"(dof[qb][2]), "v"(dof[qb][3]), "v"(Lq[qb]), "v"(Dq[qb]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the delta stores too: nothing but LDS-DMA is counted from here on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load has landed (and tile 0 with them): nothing but LDS-DMA is counted from here on
+#pragma unroll
+  for (int i = 1; i < NST - 1; ++i)
+    if (i < n) stage(i, jt_lo + i);
 
   f32x16_t dq[2][2];
 #pragma unroll
@@ -334,25 +361,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
     zero16(dq[qb][0]);
     zero16(dq[qb][1]);
   }
-
-  const int kv_hi = min(T, q0 + QB);
-  const int jt_hi = (kv_hi + KT - 1) / KT;
-  constexpr int jt_lo = 0;
-  const int n = jt_hi;
-
-  TileDma dma;
-  dma.init(wave, lane, ld);
-  auto stage = [&](int slot, int jt) {  // 4 LDS-DMA instructions per wave
-    const int kv0 = jt * KT;
-    const uint16_t* src = base + (int64_t)kv0 * ld;
-    if (kv0 + KT <= T) {
-      dma.issue_full(smem + slot * 2 * TILE, src + dm, wave);
-      dma.issue_full(smem + slot * 2 * TILE + TILE, src + 2 * dm, wave);
-    } else {
-      dma.issue(smem + slot * 2 * TILE, src + dm, ld, T - 1 - kv0, wave);
-      dma.issue(smem + slot * 2 * TILE + TILE, src + 2 * dm, ld, T - 1 - kv0, wave);
-    }
-  };
 
   // one 32-key block x one row block: S^T, dP^T, dS^T, dQ^T += K^T dS^T
   auto block = [&](int qb_, int kb, const bf16x8_t (&kfr)[4], const bf16x8_t (&vfr)[4], const bf16x8_t (&ktr)[2][2], int kv0, auto mask_tag) {
@@ -408,10 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
     }
   };
 
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)
-    if (i < n) stage(i, jt_lo + i);
-  int i = 0, slot = 0;
+  int i = 0, slot = 0;  // (tile 0 was issued in front of the row loads, tile 1 behind them)
   auto run = [&](int jt_end, auto m0_tag, auto m1_tag, bool active) {
     for (; jt_lo + i < jt_end; ++i) {
       const int rem = min(NST - 2, n - 1 - i);
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_causal_kernel(const uint16
   const RowStage rs{smem + (n % NST) * 2 * TILE + wave * 4096, lane};  // a slot nobody reads any more (see the forward kernel)
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
+    if (r0[qb] + l31 < T && hi == 0) delta[((int64_t)b * nh + h) * T + r0[qb] + l31] = Dq[qb] * dsign;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
