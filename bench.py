@@ -247,8 +247,8 @@ def claim_stdout():
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=50)   # 1.5 s of timed region at the headline shape (round 5's 20 steps were 0.6 s of a 30 s run)
+  ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--config', default='160m', choices=sorted(CONFIGS))
   ap.add_argument('--micro-batch', type=int, default=0)
   ap.add_argument('--seq-len', type=int, default=0, help='sequence length (default: the config\'s; config/config.yaml:9 ships the 160M model with 2048)')
@@ -351,7 +351,8 @@ def main():
     # Python's cyclic collector: a full collection walks every object the process holds (import torch alone creates ~10^6) and takes
     # 60-90 ms of host time - tools/step_times.py shows one such stall every few dozen steps, i.e. +3 ms per step on a 20-step region when it
     # lands inside.  Collect once here and move the survivors to the permanent generation (gc.freeze: the collector stays ON, later
-    # collections only walk what the steps themselves allocate); plainlm_amd.HipEngine does the same after its first optimizer steps.
+    # collections only walk what the steps themselves allocate); plainlm_amd.HipEngine does the same after its first optimizer step
+    # (cfg.gc_freeze, default True).
     gc.collect()
     gc.freeze()
     barrier()

@@ -478,8 +478,6 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(char* smem, const uint16_t* _
   constexpr int TILE = QT * 128;          // 8 KiB
   constexpr int STAGE = 2 * TILE + 512;   // Q | dO | statistics (lse[64], delta[64])
   constexpr int NQB = 2;                  // 32-query blocks of a query tile
-  constexpr bool LEAN = false;            // (an experiment kept for the record: statistics folded into the score accumulators, transposed fragments
-                                          //  requested behind the first MFMAs - still 74 spills at the 168 registers of three workgroups per CU)
   const int dm = nh * HD, ld = 3 * dm;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -587,32 +585,19 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(char* smem, const uint16_t* _
         const f32x4_t nd = *reinterpret_cast<const f32x4_t*>(sD + ql0);  // -delta: the dP accumulators start from it (dP' = dP - delta)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];
-        // LEAN: the score accumulators start from -LSE / c2 in the same way (p = exp2(c2 s') with s' = s - LSE / c2): the statistics die here
-        if (LEAN)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[4 * g + e] = L4[g][e] * (-1.f / c2);
       }
-      auto read_tr = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            dotr[db][s2] = frag_cols(sDO, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane);
-            qtr[db][s2] = frag_cols(sQ, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane);
-          }
-      };
-      if (!LEAN) {
-        read_tr();  // every fragment of the block is requested before its first MFMA
-        zero16(s);
-      }
+        for (int db = 0; db < 2; ++db) {  // every fragment of the block is requested before its first MFMA
+          dotr[db][s2] = frag_cols(sDO, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane);
+          qtr[db][s2] = frag_cols(sQ, db, qoff + qb * 32 + s2 * 16 + 4 * hi, lane);
+        }
+      zero16(s);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(qfr[ks], kf[ks], s);       // S[q][kv]
         dp = mfma32(dofr[ks], vf[ks], dp);    // dP'[q][kv]
-      }
-      if (LEAN) {
-        __builtin_amdgcn_sched_barrier(0);  // the row fragments are dead: the transposed ones take their registers, their latency hides behind the arithmetic below
-        read_tr();
       }
       bf16x8_t pf[2], dsf[2];
 #pragma unroll
@@ -620,7 +605,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(char* smem, const uint16_t* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          float p = LEAN ? fast_exp2(s[r] * c2) : fast_exp2(__builtin_fmaf(s[r], c2, -L4[g][e]));
+          float p = fast_exp2(__builtin_fmaf(s[r], c2, -L4[g][e]));
           if (MASK) {
             const int c = qb * 32 + 8 * g + e;
             p = ((c >= c_lo) && (c < c_end)) ? p : 0.f;

@@ -181,11 +181,12 @@ class HipEngine(torch.nn.Module):
     # next call otherwise; an update computed from a NaN loss is never applied, no micro-step goes unchecked (eval() and
     # check_losses() drain).  nan_check_lag = 0 restores the reference's order exactly; larger values defer further inside a window.
     self.nan_check_lag = int(getattr(cfg, 'nan_check_lag', 1))
-    # Optional (cfg.gc_freeze: True): after the first optimizer step, move every object alive at that point (model, optimizer,
-    # autograd function classes, caches) out of the cyclic garbage collector's generations.  Python's full collections otherwise
-    # walk all of them every few dozen steps: 10-50 ms pauses of a host loop that does 7 ms of work per step.  It is a
-    # process-wide setting, hence off unless asked for.
-    self._gc_freeze_pending = bool(getattr(cfg, 'gc_freeze', False))
+    # cfg.gc_freeze (default True since round 6; False opts out): after the first optimizer step, collect once and move every object alive at
+    # that point (model, optimizer, autograd function classes, everything `import torch` created) out of the cyclic garbage collector's
+    # generations (gc.freeze: the collector stays on).  Python's full collections otherwise walk all of them every few dozen steps: 60-90 ms
+    # stalls of a host loop that does 5-7 ms of work per step - tools/step_times.py: one step in ~30 at 90 ms instead of 9.5.
+    # A process-wide setting, but a harmless one: frozen objects are the ones a training process keeps for its whole life anyway.
+    self._gc_freeze_pending = bool(getattr(cfg, 'gc_freeze', True))
     self._unchecked, self._flag_pool = [], []
     if self.dtype != 'bfloat16':
       raise NotImplementedError(f"dtype '{self.dtype}': the gfx950 kernels implement the bfloat16 flow only")

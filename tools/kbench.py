@@ -184,8 +184,6 @@ def main():
       ds = doc_start_from_lengths(docs, T).to(dev)
       pos = torch.arange(T, device=dev)[None, :]
       fl_m = float((4.0 * nh * 64 * (pos - ds + 1)).sum())  # visible (query, key) pairs x 2 matmuls x 2 flop x head_dim
-      import os
-      from plainlm_amd import _lib
       rec('attn doc plan (once per batch)', timeit(lambda: ops.attn_doc_plan(ds, nh), a.iters))
       # the shipped kernels, and the same without heavy tiles split into 64-row items (same process, same box)
       for tag, env in (('', {}), (' [no split]', {'PLM_ATTN_DOC_SPLIT_MIN': '0'})):
