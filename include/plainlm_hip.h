@@ -152,7 +152,9 @@ int plm_gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
 
 /* ---- RoPE + causal / document-masked attention
  * (models/transformer.py:43-65, models/embeddings.py:15-30, data/datasets/data_prep_utils.py:7-23)
- * qkv bf16[B*T, 3*nh*hd] straight from w_qkv (q | k | v column blocks, head h = cols h*hd..), hd == 64, T % 4 == 0.
+ * qkv bf16[B*T, 3*nh*hd] straight from w_qkv (q | k | v column blocks, head h = cols h*hd..), T % 4 == 0; hd == 64 takes the tuned kernels
+ * described below (every shipped config), hd == 32 or 128 (models/transformer.py:34 allows any dim // n_heads) a plain kernel family
+ * (csrc/attn_generic.hip: element-wise masks, no plan needed, the inverse rotation as a separate in-place pass) behind the same entry points.
  * rope_cos/sin fp32[T, hd/2] (interleaved-pair convention).  doc_start int32[B,T] or NULL (pure causal):
  * query i attends key j iff doc_start[i] <= j <= i (doc_start non-decreasing in i).
  * plm_rope_qk : rotates the q and k blocks of qkv IN PLACE (fp32 math, bf16 result).  The training step does not launch it: the

@@ -20,8 +20,8 @@
 // The fallback of plm_qkv_rope_bf16 (shapes its fused epilogue does not take) and the yardstick of the epilogue's bit-equality tests.
 // =============================================================================================
 __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv, const float* __restrict__ rcos,
-                                                      const float* __restrict__ rsin, int64_t BT, int T, int nh) {
-  const int dm = nh * HD, ld = 3 * dm;
+                                                      const float* __restrict__ rsin, int64_t BT, int T, int nh, int hd, float sgn) {
+  const int dm = nh * hd, ld = 3 * dm;
   const int cpr = 2 * dm / 8;  // 16-byte chunks of q|k per token row
   const int64_t total = BT * cpr;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(uint16_t* __restrict__ qkv
     const int64_t row = i / cpr;
     const int c = (int)(i - row * cpr);
     const int t = (int)(row % T);
-    const int pair0 = (c * 8 % HD) / 2;
+    const int pair0 = (c * 8 % hd) / 2;
     uint16_t* p = qkv + row * ld + c * 8;
-    const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + t * (HD / 2) + pair0);
-    const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + t * (HD / 2) + pair0);
-    st_bf16x8(p, rope8(ld_bf16x8(p), cs, sn, 1.f));
+    const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(rcos + t * (hd / 2) + pair0);
+    const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rsin + t * (hd / 2) + pair0);
+    st_bf16x8(p, rope8(ld_bf16x8(p), cs, sn, sgn));  // sgn = -1: the inverse rotation (the generic backward path, attn_generic.hip)
   }
 }
 
@@ -53,22 +53,34 @@ void plm_attn_bwd_doc(const uint16_t* qkv, const uint16_t* out, const uint16_t* 
                       const float* rs, const int32_t* doc_start, const int32_t* plan, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh,
                       hipStream_t s);
 
+// head dims other than 64: attn_generic.hip
+bool plm_attn_generic_supported(int64_t hd);
+void plm_attn_fwd_generic(const uint16_t* qkv, const int32_t* doc_start, uint16_t* out, float* lse, int64_t B, int64_t T, int64_t nh, int64_t hd,
+                          hipStream_t s);
+void plm_attn_bwd_generic(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta,
+                          const int32_t* doc_start, uint16_t* dqkv, int64_t B, int64_t T, int64_t nh, int64_t hd, hipStream_t s);
+
 static int check_attn_shape(const char* name, int64_t B, int64_t T, int64_t nh, int64_t hd) {
-  PLM_REQUIRE(hd == HD, "%s: head_dim %ld unsupported (this build implements head_dim 64)", name, (long)hd);
+  PLM_REQUIRE(hd == HD || plm_attn_generic_supported(hd), "%s: head_dim %ld unsupported (64: the tuned kernels; 32, 128: the generic ones)", name, (long)hd);
   PLM_REQUIRE(B > 0 && T > 0 && nh > 0 && B < 65536 && nh < 65536 && T < (1 << 24), "%s: bad shape B=%ld T=%ld nh=%ld", name, (long)B,
               (long)T, (long)nh);
   PLM_REQUIRE(T % 4 == 0, "%s: T=%ld must be a multiple of 4", name, (long)T);
   return PLM_OK;
 }
 
+static void rope_qk_launch(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd, float sgn,
+                           hipStream_t s) {
+  const int64_t items = B * T * (2 * nh * hd / 8);
+  int64_t blocks = plm_cdiv(items, 256);
+  if (blocks > ((int64_t)1 << 20)) blocks = (int64_t)1 << 20;  // one item per thread in memory order (see elementwise_grid)
+  hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qkv, rope_cos, rope_sin, B * T, (int)T, (int)nh, (int)hd, sgn);
+}
+
 extern "C" int plm_rope_qk(uint16_t* qkv, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                            void* stream) {
   PLM_REQUIRE(qkv && rope_cos && rope_sin, "plm_rope_qk: null pointer");
   if (int rc = check_attn_shape("plm_rope_qk", B, T, nh, hd)) return rc;
-  const int64_t items = B * T * (2 * nh * hd / 8);
-  int64_t blocks = plm_cdiv(items, 256);
-  if (blocks > ((int64_t)1 << 20)) blocks = (int64_t)1 << 20;  // one item per thread in memory order (see elementwise_grid)
-  hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, qkv, rope_cos, rope_sin, B * T, (int)T, (int)nh);
+  rope_qk_launch(qkv, rope_cos, rope_sin, B, T, nh, hd, 1.f, (hipStream_t)stream);
   PLM_CHECK_LAUNCH("plm_rope_qk");
   return PLM_OK;
 }
@@ -101,7 +113,9 @@ extern "C" int plm_attn_fwd(const uint16_t* qkv, const int32_t* doc_start, const
   PLM_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "plm_attn_fwd: qkv and out must be 16-byte aligned");
   if (int rc = check_attn_shape("plm_attn_fwd", B, T, nh, hd)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (!doc_start) {
+  if (hd != HD) {
+    plm_attn_fwd_generic(qkv, doc_start, out, lse, B, T, nh, hd, s);  // (no plan: element-wise masks)
+  } else if (!doc_start) {
     plm_attn_fwd_causal(qkv, out, lse, B, T, nh, s);
   } else {
     PLM_REQUIRE(doc_plan, "plm_attn_fwd: a document mask needs its plan (plm_attn_doc_plan)");
@@ -121,7 +135,11 @@ extern "C" int plm_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
               "plm_attn_bwd: qkv, out, dout, dqkv and the RoPE tables must be 16-byte aligned");
   if (int rc = check_attn_shape("plm_attn_bwd", B, T, nh, hd)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (!doc_start) {
+  if (hd != HD) {
+    // the generic kernels return the gradient w.r.t. the ROTATED q, k; the rotation is orthogonal, so its backward is the inverse rotation
+    plm_attn_bwd_generic(qkv, out, dout, lse, delta, doc_start, dqkv, B, T, nh, hd, s);
+    rope_qk_launch(dqkv, rope_cos, rope_sin, B, T, nh, hd, -1.f, s);
+  } else if (!doc_start) {
     plm_attn_bwd_causal(qkv, out, dout, lse, delta, rope_cos, rope_sin, dqkv, B, T, nh, s);
   } else {
     PLM_REQUIRE(doc_plan, "plm_attn_bwd: a document mask needs its plan (plm_attn_doc_plan)");

@@ -370,10 +370,10 @@ extern "C" int plm_qkv_rope_bf16(const uint16_t* X, int64_t ldx, const uint16_t*
                                  int64_t K, const float* rope_cos, const float* rope_sin, int64_t B, int64_t T, int64_t nh, int64_t hd,
                                  void* stream) {
   PLM_REQUIRE(X && W && QKV && rope_cos && rope_sin, "plm_qkv_rope_bf16: null pointer");
-  PLM_REQUIRE(hd == 64 && B > 0 && T > 0 && nh > 0 && M == B * T, "plm_qkv_rope_bf16: bad shape (hd must be 64, M == B*T)");
+  PLM_REQUIRE((hd == 64 || hd == 32 || hd == 128) && B > 0 && T > 0 && nh > 0 && M == B * T, "plm_qkv_rope_bf16: bad shape (hd 32 / 64 / 128, M == B*T)");
   const int64_t N = 3 * nh * hd;
   PLM_REQUIRE(ldq == N, "plm_qkv_rope_bf16: needs a dense output (ldq == 3*nh*hd)");
-  if (!plm_env().gemm_v1 &&
+  if (hd == 64 && !plm_env().gemm_v1 &&  // the store-side rotation is built for 64-wide heads; other head dims take GEMM + the stand-alone pass
       plm_launch_gemm_nt_rope(X, ldx, W, ldw, QKV, ldq, M, N, K, rope_cos, rope_sin, T, 2 * nh * hd, (hipStream_t)stream)) {
     PLM_CHECK_LAUNCH("plm_qkv_rope_bf16");
     return PLM_OK;

@@ -218,8 +218,8 @@ class Transformer(nn.Module):
     if cfg.dim % cfg.n_heads != 0:
       raise ValueError('dim must be divisible by n_heads')
     self.head_dim = cfg.dim // cfg.n_heads
-    if self.head_dim != 64:
-      raise NotImplementedError(f'head_dim {self.head_dim}: the gfx950 attention kernel is built for head_dim 64')
+    if self.head_dim not in (32, 64, 128):  # 64: the tuned kernels (every shipped config); 32 / 128: csrc/attn_generic.hip
+      raise NotImplementedError(f'head_dim {self.head_dim}: the gfx950 attention kernels are built for head dims 32, 64 and 128')
 
     self.embed_tokens = HipEmbedding(cfg.vocab_size, cfg.dim)
     self.layers = nn.ModuleList([Block(idx, cfg) for idx in range(cfg.n_layers)])

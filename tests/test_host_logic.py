@@ -88,7 +88,8 @@ def test_unsupported_configs_fail_loudly():
     m, _ = P.construct_model(_cfg(mlp_class=kind))
     assert tuple(m.layers[0].mlp.fc1.weight.shape) == (512, 128) and tuple(m.layers[0].mlp.fc2.weight.shape) == (128, 512)
   with pytest.raises(NotImplementedError):
-    P.construct_model(_cfg(n_heads=4))  # head_dim 32
+    P.construct_model(_cfg(n_heads=8))  # head_dim 16: below the 32 / 64 / 128 the attention kernels are built for
+  assert P.construct_model(_cfg(n_heads=4))[0].head_dim == 32 and P.construct_model(_cfg(n_heads=1))[0].head_dim == 128
   with pytest.raises(ValueError):
     P.construct_model(_cfg(d_model=100, n_heads=3))
 
@@ -357,7 +358,7 @@ def test_register_budget_of_the_attention_and_128x128_gemm_kernels():
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   seen = 0
-  for f in ('attn_causal.hip', 'attn_doc.hip', 'gemm.hip'):
+  for f in ('attn_causal.hip', 'attn_doc.hip', 'attn_generic.hip', 'gemm.hip'):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'isa_scan.py'), f], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()
@@ -375,5 +376,5 @@ def test_register_budget_of_the_attention_and_128x128_gemm_kernels():
         if 'attn_fwd_doc_kernel' in name or 'attn_bwd_dq_doc_kernel' in name:
           # three workgroups per CU (768 resident workgroups = the whole grid of config_doc_mask.yaml's micro-batch): 512 / 3 registers per lane
           assert meta['vgpr'] <= 168, (name, meta)
-  assert seen >= 16, seen
+  assert seen >= 22, seen
 

@@ -557,8 +557,7 @@ def test_gemm_linearity(ops):
 # --------------------------------------------------------------------------------------
 # attention (with in-kernel RoPE) vs the oracle
 # --------------------------------------------------------------------------------------
-def _attn_ref(qkv, B, T, nh, doc_start):
-  hd = 64
+def _attn_ref(qkv, B, T, nh, doc_start, hd=64):
   cos, sin = O.rope_table(hd, T)
   q, k, v = (t.reshape(B, T, nh, hd) for t in qkv.float().split(nh * hd, dim=1))
   qr = O.rope_apply(q, cos, sin)
@@ -752,6 +751,69 @@ def test_doc_start_from_the_references_bool_mask(ops, B, T):
     P.Transformer._doc_start(mask.cuda(), B, T)
   assert torch.equal(P.Transformer._doc_start(mask.cuda(), B, T).cpu(), ds)
   P.Transformer.check_mask_status()
+
+
+def test_attention_doc_masks_random_shapes(ops):
+  """Seeded sweep over shapes no hand-picked case has: T from 4 to ~700 in steps of 4 (shorter than a key tile, one row over a tile edge, ragged
+  last tiles of 128-row items and of their 64-row halves), 1-4 sequences, 1-3 heads, document lengths from one token to the whole row - forward +
+  backward against the oracle, causal twin (one document per row) against the causal kernels."""
+  rng = np.random.default_rng(20261002)
+  for case in range(24):
+    B, nh = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    T = 4 * int(rng.integers(1, 176)) if case % 3 else 4 * int(rng.integers(1, 20))
+    mean = float(rng.choice([1.5, 7, 40, 150, 400, 2000]))
+    docs = []
+    for _ in range(B):
+      lens, tot = [], 0
+      while tot < T + 1:
+        n = int(min(rng.geometric(1.0 / mean), T + 1 - tot))
+        lens.append(n)
+        tot += n
+      docs.append(lens)
+    g = torch.Generator().manual_seed(case)
+    d = nh * 64
+    qkv = bf(torch.randn(B * T, 3 * d, generator=g))
+    dout = bf(torch.randn(B * T, d, generator=g))
+    ds = O.doc_start_from_lengths(docs, T)
+    leaf = qkv.float().requires_grad_(True)
+    ref = _attn_ref(leaf, B, T, nh, ds)
+    ref.backward(dout.float())
+    cos, sin = (t.cuda() for t in O.rope_table(64, T))
+    qrot = ops.rope_qk_(qkv.cuda(), cos, sin, B, T, nh)
+    out, lse = ops.attn_fwd(qrot, B, T, nh, ds.cuda())
+    tag = f'case {case}: B={B} T={T} nh={nh} mean doc {mean}'
+    close(out.float(), ref, 1.6e-2, 'attention out, ' + tag)
+    dqkv = ops.attn_bwd(qrot, out, dout.cuda(), lse, cos, sin, B, T, nh, ds.cuda())
+    scale = leaf.grad.abs().max().item()
+    for name, got, want in zip('qkv', dqkv.split(d, dim=1), leaf.grad.split(d, dim=1)):
+      err = (got.float().cpu() - want).abs().max().item()
+      assert err <= 2e-2 * max(want.abs().max().item(), 0.05 * scale), (tag, name, err)  # (short documents: dQ / dK are nearly zero, judged on dV's scale)
+
+
+@pytest.mark.parametrize('hd', [32, 128])
+@pytest.mark.parametrize('B,T,nh,masked', [(2, 64, 2, False), (1, 200, 3, True), (2, 512, 2, True), (1, 1024, 2, False), (3, 328, 1, True)])
+def test_attention_other_head_dims(ops, hd, B, T, nh, masked):
+  """models/transformer.py:34 allows any dim // n_heads; 64 is what every shipped config has and what the tuned kernels serve.  Head dims 32 and
+  128 take the plain kernel family of csrc/attn_generic.hip behind the same entry points (RoPE by the stand-alone pass, element-wise masks, the
+  inverse rotation as an in-place pass over dQ | dK): forward + backward vs the oracle, causal and with document masks, ragged T, bit-reproducible."""
+  g = torch.Generator().manual_seed(hd * T + nh + masked)
+  d = nh * hd
+  qkv = bf(torch.randn(B * T, 3 * d, generator=g))
+  dout = bf(torch.randn(B * T, d, generator=g))
+  ds = O.doc_start_from_lengths(_random_docs(B, T, T + hd), T) if masked else None
+  leaf = qkv.float().requires_grad_(True)
+  ref = _attn_ref(leaf, B, T, nh, ds, hd=hd)
+  ref.backward(dout.float())
+  cos, sin = (t.cuda() for t in O.rope_table(hd, T))
+  dsg = None if ds is None else ds.cuda()
+  qrot = ops.rope_qk_(qkv.cuda(), cos, sin, B, T, nh)
+  out, lse = ops.attn_fwd(qrot, B, T, nh, dsg)
+  close(out.float(), ref, 1.6e-2, f'attention out (hd {hd})')
+  dqkv = ops.attn_bwd(qrot, out, dout.cuda(), lse, cos, sin, B, T, nh, dsg)
+  for name, got, want in zip('qkv', dqkv.split(d, dim=1), leaf.grad.split(d, dim=1)):
+    close(got.float(), want, 2e-2, f'attention d{name} (hd {hd})')
+  out2, lse2 = ops.attn_fwd(qrot, B, T, nh, dsg)
+  assert torch.equal(out, out2) and torch.equal(dqkv, ops.attn_bwd(qrot, out2, dout.cuda(), lse2, cos, sin, B, T, nh, dsg))
 
 
 def test_attention_doc_requires_plan_at_the_c_abi(ops):

@@ -293,6 +293,28 @@ def test_plain_mlp_classes_vs_reference(P, golden_dir, kind):
     assert len(worst) == 15 and max(worst.values()) < 4e-2, worst
 
 
+@pytest.mark.parametrize('nh,masked', [(4, False), (4, True), (1, False)])
+def test_model_other_head_dims_vs_oracle(P, nh, masked):
+  """A 2-layer d = 128 model with 4 heads (head_dim 32: the reference's default-style tiny config) and with 1 head (head_dim 128): loss within
+  1e-4 and all 15 gradients against the fp32 oracle, causal and with document masks - the generic attention kernels, GEMM + stand-alone RoPE,
+  through the same module API."""
+  ocfg = O.OracleConfig(vocab_size=512, seq_len=128, dim=128, n_layers=2, n_heads=nh)
+  w = O.init_params(ocfg, seed=17 + nh)
+  rng = np.random.default_rng(nh)
+  tok = torch.from_numpy(rng.integers(0, 512, size=(3, 129)))
+  ids, tgt = tok[:, :128], tok[:, 1:]
+  ds = O.doc_start_from_lengths([[40, 50, 39], [129], [1, 100, 28]], 128) if masked else None
+  m = P.Transformer(P.ModelConfig(vocab_size=512, seq_len=128, dim=128, expand=8 / 3, n_layers=2, n_heads=nh, mlp='glu'))
+  m.load_state_dict(w)
+  m = m.cuda()
+  loss = m.loss(ids.cuda(), tgt.contiguous().cuda(), None if ds is None else ds.cuda())
+  loss.backward()
+  oloss, og = O.loss_and_grads(w, ocfg, ids, tgt, ds)
+  assert abs(loss.item() - oloss.item()) <= LOSS_RTOL * abs(oloss.item()), (loss.item(), oloss.item())
+  worst = {n: relmax(p.grad.float().cpu(), og[n]) for n, p in m.named_parameters()}
+  assert len(worst) == 15 and max(worst.values()) < 4e-2, worst
+
+
 def test_engine_cfg1_literal_shape_vs_reference(P, golden_dir):
   """BASELINE configs[0] at its literal shape through HipEngine on the GPU: 2 layers, d = 128, 2 heads, seq 128, the REAL vocabulary
   (50 280: with d = 128 the ragged lm_head and its gradient GEMMs take the small-shape kernels no other model-level test reaches),
