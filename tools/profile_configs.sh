@@ -11,6 +11,10 @@ export TMPDIR=/tmp
 R=$PWD
 python bench.py --config 420m > $O/bench_420m.json 2> $O/bench_420m.err; echo "bench 420m rc=$?"
 python bench.py --doc-mask --micro-batch 8 > $O/bench_docmask_b8.json 2> $O/bench_docmask_b8.err; echo "bench doc-mask B=8 rc=$?"
+# the reference's configs AS SHIPPED: seq_len 2048 for the 160M model (config/config.yaml:9,33: micro-batch 32; config_doc_mask.yaml:9,35: micro-batch 8 + document masks)
+python bench.py --seq-len 2048 --no-extras > $O/bench_160m_t2048.json 2> $O/bench_160m_t2048.err; echo "bench 160M T=2048 B=32 rc=$?"
+python bench.py --seq-len 2048 --doc-mask --micro-batch 8 --no-extras > $O/bench_160m_t2048_docmask_b8.json 2> $O/bench_160m_t2048_docmask_b8.err; echo "bench 160M T=2048 doc masks B=8 rc=$?"
+python tools/kbench.py --iters 10 --T 2048 --only gemm,attn,hbm --json $O/kbench_160m_t2048.jsonl > $O/kbench_160m_t2048.log 2>&1; echo "kbench 160M T=2048 rc=$?"
 python tools/kbench.py --iters 20 --config 420m --only gemm,attn,hbm --json $O/kbench_420m.jsonl > $O/kbench_420m.log 2>&1; echo "kbench 420m rc=$?"
 python tools/kbench.py --iters 20 --B 8 --doc-mask --only gemm,attn,hbm --json $O/kbench_docmask_b8.jsonl > $O/kbench_docmask_b8.log 2>&1; echo "kbench B=8 rc=$?"
 summ() {  # $1 = trace dir, $2 = output file, $3 = command line text
