@@ -1,7 +1,10 @@
 """bench.py — throughput of the plainLM hot path (fwd+bwd of the 160M decoder at seq 1024, bf16)
 on N MI355X GPUs of one node, one process per GPU.
 
+  python bench.py                                (N = 1, 50 timed steps after 10 warm-up steps)
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --config 160m --seq-len 2048  (the reference's yaml files as shipped: tr_160M_x8gpu.yaml has seq_len 2048)
+  python bench.py --doc-mask --micro-batch 8    (config_doc_mask.yaml's document-masked batches)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
   python bench.py --gpus N ...      (no launcher: the parent, which never touches a GPU, starts the N rank processes itself)
@@ -12,8 +15,9 @@ per forward) and, for N > 1, the bucketed RCCL gradient all-reduce overlapped wi
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 After the timed region rank 0 also (untimed) measures: the same step with per-launch HIP events
-for the roofline object, a full training step (clip + AdamW) for reference, and — at N = 1 —
-the CPU oracle on the host cores as ``cpu_baseline``.
+for the roofline object (the dominant MFMA family, plus the HBM-bound kernel families under
+``roofline.hbm``), a full training step (clip + AdamW) for reference, and — at N = 1 —
+the CPU oracle on the host cores as ``cpu_baseline`` (a bounded sample of about 10 s).
 """
 
 import argparse

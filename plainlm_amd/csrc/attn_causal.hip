@@ -1,6 +1,6 @@
-// Causal attention (no document masks) for gfx950, second generation of kernels: forward, backward dQ, backward dK / dV.
-// Same math, LDS image, LDS-DMA staging and C ABI as attn.hip (whose kernels keep serving document-masked batches: their 128-row
-// tiles skip more of a block-diagonal mask); q, k are already rotated (RoPE lives in the w_qkv GEMM's epilogue).
+// Causal attention (no document masks) for gfx950, second generation of kernels: forward, backward dQ, backward dK / dV - and, as its DOC mode,
+// the dK / dV kernel of document-masked batches (forward / dQ of those: attn_doc.hip, which shares the LDS image, the LDS-DMA staging and the
+// C ABI of attn.hip with this file); q, k are already rotated (RoPE lives in the w_qkv GEMM's epilogue).
 //
 // What round 3 measured on the first-generation kernels (profiles/r03_attn_ablation.txt, r03_ubench_mfma_gap.txt: timing-only ablations, SQ counters,
 // tools/ubench/mfma_gap.hip) and what these kernels do about it:
@@ -26,7 +26,8 @@
 
 #include "attn_common.h"
 
-// Block -> (row tile of RB rows, head, batch), heaviest (latest) tiles first: see attn_block() in attn.hip.  (Head-major orders that let the
+// Block -> (row tile of RB rows, head, batch), heaviest (latest) tiles first: the hardware hands workgroups out in blockIdx order, so ALL blocks
+// of the heaviest tile index come first, the lightest last (longest-processing-time-first).  (Head-major orders that let the
 // tiles of a head meet in their XCD's L2 are slower - load balance is worth more than L2 hits: profiles/r04_attn_pingpong.txt section 3.)
 template <int RB>
 __device__ __forceinline__ void attn_block2(int T, int nh, int& tile, int& h, int& b) {

@@ -1,21 +1,25 @@
-// Attention with document masks (doc_start[B,T]: query i sees key j iff doc_start[i] <= j <= i), third generation: the plan kernel,
-// forward and backward dQ.  (Backward dK / dV is the DOC mode of attn_bwd_dkdv_kernel in attn_causal.hip.)
+// Attention with document masks (doc_start[B,T]: query i sees key j iff doc_start[i] <= j <= i), third generation: the plan kernel, the
+// bool-mask conversion, forward and backward dQ.  (Backward dK / dV is the DOC mode of attn_bwd_dkdv_body in attn_causal.hip.)
 // Replaces F.scaled_dot_product_attention(q, k, v, attn_mask=...) of models/transformer.py:52-61 with the masks of
 // data/datasets/data_prep_utils.py:7-23.
 //
-// What was wrong with the second-generation kernels at the reference's own micro-batch (config_doc_mask.yaml:35, B = 8: 768 workgroups, every one
-// of them resident at once; profiles/r05_pmc_docmask_b8.txt: MFMA utilisation 0.09-0.12) and what this file does about it:
-//   * The work of a 128-row tile is the number of 64-key tiles between the first document of its rows and its diagonal: 2 ... 16 at T = 1024 with a mean
-//     of 5.  The grid was ordered by tile INDEX (the causal kernels' heaviest-first order), so a CU's three workgroups were a random draw: the
-//     worst CU carried ~28 tile steps per SIMD against a mean of 15, and the kernel lasts as long as its worst CU.  A tiny PLAN kernel (once per
-//     batch: every layer's forward, dQ and dK/dV launches share it) sorts the tiles by their actual cost; the grid walks that list (attn_common.h).
+// What a per-workgroup trace (tools/attn_trace.py) showed about the second-generation kernels at the reference's own micro-batch
+// (config_doc_mask.yaml:35, B = 8: 768 workgroups, every one of them resident at once; MFMA utilisation 0.09-0.12) and what this file does about it:
+//   * The work of a 128-row tile is the number of 64-key tiles between the first document of its rows and its diagonal: 2 ... 16 at T = 1024 with a
+//     mean of 5 - and a launch whose whole grid is resident lasts as long as its LONGEST workgroup (most ended after 11-13 us, the twelve with 14
+//     tile steps after 22.5).  The grid was ordered by tile INDEX (the causal kernels' heaviest-first order), which says nothing about cost here.  A
+//     small PLAN kernel (once per batch: every layer's forward, dQ and dK/dV launches share it) sorts the tiles by their actual cost, and - when the
+//     grid is resident at once - enters the heaviest query tiles as two 64-row items whose four waves are 2 row blocks x 2 halves of every key tile:
+//     half the chain of dependent tile steps, partial results merged once through LDS (attn_common.h has the plan's layout).
 //   * The dK/dV kernel found its last query tile with a loop of DEPENDENT scalar loads (one per query tile: up to 16 x ~0.7 us in front of the first DMA);
 //     the plan carries it, and a per-key doc_end[] turns that kernel's mask into two integer thresholds per lane - the causal kernel's own form.
-//   * Two LDS stages with a draining vmcnt(0) per tile -> the causal kernels' NST-deep ring with counted waits.
+//   * A workgroup cost ~10 us before its first and after its last tile step.  Two LDS stages with a draining vmcnt(0) per tile -> the causal kernels'
+//     NST-deep ring with counted waits, tile 0 issued in front of the row loads; the wave's own rows by LDS-DMA (whole 128-byte rows instead of
+//     fragment loads that touch 32 lines per instruction); the inverse RoPE rotation on the store side of the epilogue (RowStage::flush_rot).
 //   * Every tile took the element-wise mask (five VALU instructions per score) -> per WAVE the tiles fall into idle / masked / unmasked / masked / idle
 //     segments (doc_start is non-decreasing, so a wave's first and last rows bound all of them): static loops like the causal kernels', masks are two
 //     integer thresholds per lane, the forward softmax defers its rescale.
-// Waves stay at 32 rows (4 per 128-row tile): at B = 8 the kernels are bound by the longest chain of dependent tile steps, not by LDS reads per MFMA.
+// Waves stay at 32 rows: at B = 8 the kernels are bound by the longest chain of dependent tile steps and by fixed costs, not by LDS reads per MFMA.
 #include "plm_device.h"
 
 #include <type_traits>
