@@ -121,13 +121,21 @@ def test_kernel_sections_within_the_committed_floors():
   floors = json.load(open(FLOORS))['us_per_launch']
   got = measure()
   assert set(got) == set(floors), sorted(set(got) ^ set(floors))
-  print('section: measured us / committed floor us (ratio)')
-  slow = {}
-  for k, us in got.items():
-    print(f'  {k:40s} {us:9.1f} / {floors[k]:9.1f}  ({us / floors[k]:.2f})')
-    if us > floors[k] / MARGIN:
-      slow[k] = (us, floors[k])
-  assert not slow, f'sections slower than 1 / {MARGIN} x their committed time (measured us, floor us): {slow}'
+  def report(got):
+    print('section: measured us / committed floor us (ratio)')
+    slow = {}
+    for k, us in got.items():
+      print(f'  {k:40s} {us:9.1f} / {floors[k]:9.1f}  ({us / floors[k]:.2f})')
+      if us > floors[k] / MARGIN:
+        slow[k] = (us, floors[k])
+    return slow
+  slow = report(got)
+  if slow:
+    # a regression is slow every time, a disturbance (another process on the box, a clock ramp after an idle stretch) is not: measure once
+    # more and fail only on the sections that are slow in BOTH passes
+    again = report(measure())
+    slow = {k: (v[0], again[k], v[1]) for k, v in slow.items() if again[k] > floors[k] / MARGIN}
+  assert not slow, f'sections slower than 1 / {MARGIN} x their committed time in two passes (measured us, measured again us, floor us): {slow}'
 
 
 if __name__ == '__main__':
