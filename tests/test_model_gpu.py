@@ -635,7 +635,9 @@ def test_160m_loss_and_grad_parity_vs_oracle(P):
   loss = m.loss(ids.cuda(), tgt.cuda())
   loss.backward()
   m.attach_grads()
-  torch.set_num_threads(max(1, os.cpu_count() or 1))
+  # 32 threads: the oracle's best on the pool's hosts (bench.py's cpu_baseline: 450 tok/s at 32 threads, 140 at 128; with all 256 logical CPUs this
+  # call took 250 s - half of the GPU suite)
+  torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
   oloss, og = O.loss_and_grads(w, ocfg, ids, tgt)
   rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
   print(f'160M loss gpu {loss.item():.6f} cpu {oloss.item():.6f} rel {rel:.2e}')
