@@ -471,6 +471,24 @@ def main():
     # (n1_ms lives on rank 0 only - the rank that prints; no collective here: the other ranks never measured it)
     out['comm'] = comm_info(alt_default, per_rank, stats=run_stats)
 
+  def bail(line_out, deadline_t):
+    """Leave from a failure path of an untimed leg: rank 0 prints `line_out` (a complete line of a finished timed region) and exits 0; the other
+    ranks exit 3 (the failure stays visible to the launcher) - but only after rank 0 has had its chance: a launcher (torch.distributed.run,
+    spawn_ranks) kills every rank as soon as one exits non-zero, and rank 0 may learn of the failure only from its own watchdog, at
+    `deadline_t` (time.monotonic() of the armed watchdog; None: the watchdogs themselves are firing, all ranks within moments)."""
+    if rank == 0:
+      for attempt in range(5):
+        try:
+          text = json.dumps(line_out)
+          break
+        except RuntimeError:  # a watchdog thread serialising the dict while the main thread adds a key
+          time.sleep(0.02)
+      os.write(json_fd, (text + '\n').encode())
+      os._exit(0)
+    grace = float(os.environ.get('PLM_BENCH_EXIT_GRACE', '5'))
+    time.sleep(max(0.0, (deadline_t or 0.0) - time.monotonic()) + grace)
+    os._exit(3)
+
   # ---- data-parallel autotune (untimed): capped communicators (ncclCommSplit, maxCTAs 8 / 16), then every alternative of {all-reduce,
   # reduce-scatter + all-gather} x {no reserve, 8, 16 CUs} x {tail bucket on the capped communicator, on the uncapped root} for a few steps
   # each; the ranks agree on the winner (the alternative whose SLOWEST rank is fastest); if it is not the first one it is then timed over the
@@ -483,11 +501,10 @@ def main():
     def give_up():
       first_out['comm']['autotune'] = f'did not finish within {deadline:.0f} s: this line is the timed run on the simplest data plane'
       first_out['autotune_ok'] = False
-      if rank == 0:
-        os.write(json_fd, (json.dumps(first_out) + '\n').encode())
-      os._exit(0 if rank == 0 else 3)  # rank 0 has printed a valid line; the others report the failure through their exit code
+      bail(first_out, None)  # rank 0 prints a valid line; the others report the failure through their exit code
     dog = threading.Timer(deadline, give_up)
     dog.daemon = True
+    dog_t = time.monotonic() + deadline
     dog.start()
     try:
       n_try = int(os.environ.get('PLM_BENCH_AUTOTUNE_STEPS', '4'))
@@ -521,79 +538,97 @@ def main():
       traceback.print_exc()
       first_out['comm']['autotune'] = f'failed on rank {rank} ({type(e).__name__}: {e}): this line is the timed run on the simplest data plane'
       first_out['autotune_ok'] = False
-      if rank == 0:
-        os.write(json_fd, (json.dumps(first_out) + '\n').encode())
-      os._exit(0 if rank == 0 else 3)  # the other ranks may be inside a collective: no clean shutdown to wait for
+      bail(first_out, dog_t)  # the other ranks may be inside a collective: no clean shutdown to wait for
     dog.cancel()
   ms_per_step = out['ms_per_step']
   reducer = st['reducer']
 
-  if not a.no_extras:
-    # ---- roofline leg: identical steps with HIP events around every MFMA kernel launch (untimed) ----
-    ops.PROFILE = []
-    n_prof = 3
-    for i in range(n_prof):
-      fwd_bwd(i)
-    torch.cuda.synchronize()
-    fam = {}
-    for name, fl, s, e in ops.PROFILE:
-      acc = fam.setdefault(name, [0.0, 0.0, 0])
-      acc[0] += fl
-      acc[1] += s.elapsed_time(e)
-      acc[2] += 1
-    ops.PROFILE = None
-    fams = {k: {'TFLOP/s': round(v[0] / v[1] / 1e9, 1), 'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof,
-                'avg_launch_ms': round(v[1] / v[2], 4)} for k, v in fam.items() if not k.startswith('hbm:')}
-    # the HBM-bound kernels (north_star: achieved HBM GB/s on the norm / activation kernels): algorithmic bytes of SURVEY.md section 8d
-    # (12 M d / 16 M d for the norms with their fused adds, 4 M V for cross-entropy in place, 8 B per parameter for the weight casts) over
-    # HIP-event time of the same untimed replay
-    hbm = {k[4:]: {'GB/s': round(v[0] / v[1] / 1e6, 1), 'frac_of_8TBps': round(v[0] / v[1] / 1e6 / PEAK_HBM_GBPS, 4),
-                   'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof, 'avg_launch_ms': round(v[1] / v[2], 4),
-                   'algorithmic_MB_per_launch': round(v[0] / v[2] / 1e6, 1)} for k, v in fam.items() if k.startswith('hbm:')}
-    dom = max(fams, key=lambda k: fams[k]['ms_per_step'])
-    out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': fams[dom]['TFLOP/s'], 'peak': PEAK_BF16_TFLOPS,
-                       'unit': 'TFLOP/s', 'frac': round(fams[dom]['TFLOP/s'] / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-                       'families': fams, 'hbm': hbm,
-                       'families_note': 'gemm_nt = plain NT GEMM launches; gemm_nt_fused = NT launches whose epilogue also does RoPE / SwiGLU / '
-                                        'SwiGLU backward (TFLOP/s counts the GEMM flops only, the time includes the fused pass)'}
-    out['roofline'].update(pmc_traffic(dom, a.config, B * T, c['n_layers']))
-
-    # ---- full training step (clip + AdamW) for reference, same data (untimed leg) ----
-    if rank == 0 or world > 1:
-      # the engine's optimizer tail (plainlm_amd/optim.py): ||g|| reduction + clip folded into one fused AdamW launch per
-      # weight-decay group, on flat buffers.  NOTE: it re-lays parameters/gradients, so it runs after the legs above.
-      import plainlm_amd as P
-      from plainlm_amd.optim import FlatAdamW
-      opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
-      if reducer is not None:  # FlatAdamW has re-laid the gradient spans: a new bucket plan on the same (selected) data plane
-        reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
-                                  reserve_cus=reducer.reserve_cus, writers=model.grad_writers(), comm_tail=reducer.comm_tail,
-                                  groups=model.grad_groups(), algo=reducer.algo)
-        model.sink.on_ready = reducer.param_ready
-        model.sink.on_queued = reducer.param_queued
-        st['reducer'] = reducer
-
-      def full(i):
-        fwd_bwd(i, recast=not opt.emits_shadows)  # FlatAdamW writes the bf16 shadows of the weights it has just updated
-        opt.clip_and_step(1.0)
-
-      for i in range(2):
-        full(i)
+  # ---- untimed legs.  The contract's measurement exists at this point: whatever happens below (an exception, or - data-parallel runs - a
+  # collective of a leg that never returns) rank 0 still prints the line, with what the legs have added so far and an `extras_error` note.
+  extras_dog, extras_t = None, None
+  def extras_failed(why, deadline_t):
+    out['extras_error'] = why
+    bail(out, deadline_t)
+  if not a.no_extras and world > 1:
+    import threading
+    extras_deadline = float(os.environ.get('PLM_BENCH_EXTRAS_TIMEOUT', '300'))
+    extras_dog = threading.Timer(extras_deadline, lambda: extras_failed(f'the untimed legs did not finish within {extras_deadline:.0f} s', None))
+    extras_dog.daemon = True
+    extras_t = time.monotonic() + extras_deadline
+    extras_dog.start()
+  try:
+    if not a.no_extras:
+      # ---- roofline leg: identical steps with HIP events around every MFMA kernel launch (untimed) ----
+      ops.PROFILE = []
+      n_prof = 3
+      for i in range(n_prof):
+        fwd_bwd(i)
       torch.cuda.synchronize()
-      t1 = time.perf_counter()
-      nfull = max(3, a.steps // 4)
-      for i in range(nfull):
-        full(i)
-      torch.cuda.synchronize()
-      full_ms = 1e3 * (time.perf_counter() - t1) / nfull
-      out['full_step'] = {'ms_per_step': round(full_ms, 3), 'tokens_per_sec_per_gpu': round(B * T / full_ms * 1e3, 1),
-                          'over_fwd_bwd_ms': round(full_ms - ms_per_step, 3),
-                          'note': 'fwd+bwd + global-norm clip + AdamW (plainlm_amd FlatAdamW kernels; rank-local clock, untimed leg)'
-                                  + ('; the AdamW launch also emits the bf16 weight shadows, so this leg has no stand-alone weight cast'
-                                     if opt.emits_shadows else '')}
+      fam = {}
+      for name, fl, s, e in ops.PROFILE:
+        acc = fam.setdefault(name, [0.0, 0.0, 0])
+        acc[0] += fl
+        acc[1] += s.elapsed_time(e)
+        acc[2] += 1
+      ops.PROFILE = None
+      fams = {k: {'TFLOP/s': round(v[0] / v[1] / 1e9, 1), 'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof,
+                  'avg_launch_ms': round(v[1] / v[2], 4)} for k, v in fam.items() if not k.startswith('hbm:')}
+      # the HBM-bound kernels (north_star: achieved HBM GB/s on the norm / activation kernels): algorithmic bytes of SURVEY.md section 8d
+      # (12 M d / 16 M d for the norms with their fused adds, 4 M V for cross-entropy in place, 8 B per parameter for the weight casts) over
+      # HIP-event time of the same untimed replay
+      hbm = {k[4:]: {'GB/s': round(v[0] / v[1] / 1e6, 1), 'frac_of_8TBps': round(v[0] / v[1] / 1e6 / PEAK_HBM_GBPS, 4),
+                     'ms_per_step': round(v[1] / n_prof, 3), 'launches_per_step': v[2] // n_prof, 'avg_launch_ms': round(v[1] / v[2], 4),
+                     'algorithmic_MB_per_launch': round(v[0] / v[2] / 1e6, 1)} for k, v in fam.items() if k.startswith('hbm:')}
+      dom = max(fams, key=lambda k: fams[k]['ms_per_step'])
+      out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': fams[dom]['TFLOP/s'], 'peak': PEAK_BF16_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(fams[dom]['TFLOP/s'] / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                         'families': fams, 'hbm': hbm,
+                         'families_note': 'gemm_nt = plain NT GEMM launches; gemm_nt_fused = NT launches whose epilogue also does RoPE / SwiGLU / '
+                                          'SwiGLU backward (TFLOP/s counts the GEMM flops only, the time includes the fused pass)'}
+      out['roofline'].update(pmc_traffic(dom, a.config, B * T, c['n_layers']))
 
-    if world == 1:
-      out['cpu_baseline'] = cpu_baseline(c)
+      # ---- full training step (clip + AdamW) for reference, same data (untimed leg) ----
+      if rank == 0 or world > 1:
+        # the engine's optimizer tail (plainlm_amd/optim.py): ||g|| reduction + clip folded into one fused AdamW launch per
+        # weight-decay group, on flat buffers.  NOTE: it re-lays parameters/gradients, so it runs after the legs above.
+        import plainlm_amd as P
+        from plainlm_amd.optim import FlatAdamW
+        opt = FlatAdamW(model, P.get_param_groups(model, 0.1), lr=1e-4, betas=[0.9, 0.95], eps=1e-8, weight_decay=0.1)
+        if reducer is not None:  # FlatAdamW has re-laid the gradient spans: a new bucket plan on the same (selected) data plane
+          reducer = ddp.GradReducer(flat, params, model._grad_spans, reducer.comm, bucket_cap_mb=a.bucket_mb, force=reducer.force,
+                                    reserve_cus=reducer.reserve_cus, writers=model.grad_writers(), comm_tail=reducer.comm_tail,
+                                    groups=model.grad_groups(), algo=reducer.algo)
+          model.sink.on_ready = reducer.param_ready
+          model.sink.on_queued = reducer.param_queued
+          st['reducer'] = reducer
+
+        def full(i):
+          fwd_bwd(i, recast=not opt.emits_shadows)  # FlatAdamW writes the bf16 shadows of the weights it has just updated
+          opt.clip_and_step(1.0)
+
+        for i in range(2):
+          full(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nfull = max(3, a.steps // 4)
+        for i in range(nfull):
+          full(i)
+        torch.cuda.synchronize()
+        full_ms = 1e3 * (time.perf_counter() - t1) / nfull
+        out['full_step'] = {'ms_per_step': round(full_ms, 3), 'tokens_per_sec_per_gpu': round(B * T / full_ms * 1e3, 1),
+                            'over_fwd_bwd_ms': round(full_ms - ms_per_step, 3),
+                            'note': 'fwd+bwd + global-norm clip + AdamW (plainlm_amd FlatAdamW kernels; rank-local clock, untimed leg)'
+                                    + ('; the AdamW launch also emits the bf16 weight shadows, so this leg has no stand-alone weight cast'
+                                       if opt.emits_shadows else '')}
+
+      if world == 1:
+        out['cpu_baseline'] = cpu_baseline(c)
+  except Exception as e:  # noqa: BLE001 - the timed region's line must survive the untimed legs
+    import traceback
+    traceback.print_exc()
+    extras_failed(f'untimed leg failed on rank {rank} ({type(e).__name__}: {e})', extras_t)
+  if extras_dog is not None:
+    extras_dog.cancel()
 
   if rank == 0:
     os.write(json_fd, (json.dumps(out) + '\n').encode())

@@ -184,12 +184,16 @@ def test_bench_two_ranks_on_one_device():
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--single-device', '--steps', '2', '--warmup', '1',
-                      '--no-extras'], cwd=root, env=env, capture_output=True, text=True, timeout=840)
+  # no --no-extras: the driver's command line.  The untimed legs (per-launch events for `roofline`, the full training step on a re-planned
+  # reducer) run their collectives on every rank too.
+  cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--single-device', '--steps', '2', '--warmup', '1']
+  r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=840)
   assert r.returncode == 0, r.stderr[-3000:]
   lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
   out = json.loads(lines[0])
+  assert 'extras_error' not in out and out['roofline']['families']['gemm_nt']['launches_per_step'] == 62 and out['full_step']['ms_per_step'] > 0
+  assert 'cpu_baseline' not in out  # rank 0 at N = 1 only
   assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
   assert out['comm']['ranks'] == 2 and out['comm']['buckets'] >= 2
   # the data-parallel line measures its own N = 1 (rank 0 alone, before the data plane exists) and tunes its data plane by consensus
@@ -198,6 +202,13 @@ def test_bench_two_ranks_on_one_device():
   assert out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
   assert 'PLUMBING CHECK ONLY' in out['data']
   assert out['value'] > 0 and np.isfinite(out['loss']) and 10.0 < out['loss'] < 12.0  # ln(50280) = 10.83 at init
+  # an untimed leg that never returns (a collective on a first multi-GPU contact) must not cost the measurement: the watchdog prints the line
+  # of the timed region with an `extras_error` note
+  r = subprocess.run(cmd + ['--no-autotune'], cwd=root, env=dict(env, PLM_BENCH_EXTRAS_TIMEOUT='0.001'), capture_output=True, text=True, timeout=840)
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+  out = json.loads(lines[0])
+  assert 'did not finish' in out['extras_error'] and out['value'] > 0 and out['n_gpus'] == 2 and out['comm']['ranks'] == 2
 
 
 _DDP_WRAPPER_SCRIPT = r'''
