@@ -34,6 +34,9 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails under the legacy mode); the variable is read when HIP
+# initialises, which nothing above has done (importing torch does not)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_HBM_GBPS = 8000.0     # HBM3E peak (MI355X_MICROARCH.md: ~8 TB/s)
