@@ -137,12 +137,21 @@ _embed_ws = {}
 def embed_bwd_sorted(ids, dout, dW, accumulate):
   """dW[v] (+)= sum of dout rows of the tokens with id v, in token order, without atomics (bit-reproducible); with
   accumulate=False every row of dW is written (zeros for unused ids).  Returns False when the shape is not supported
-  (M > 65536 tokens or V >= 65536) - the caller then falls back to embed_bwd."""
+  (V >= 65536) - the caller then falls back to embed_bwd.  The launch sorts at most 65536 tokens (16-bit positions in its keys); longer
+  batches go through it in slices of that many tokens, every slice after the first accumulating onto the previous ones - still in token
+  order, still without atomics."""
   ids = ids.reshape(-1)
   _need(ids, torch.int64, 'embed_bwd_sorted.ids')
   _need(dout, F32, 'embed_bwd_sorted.dout', 2)
   _need(dW, F32, 'embed_bwd_sorted.dW', 2)
   lib = _lib.load()
+  M, lim = ids.numel(), 65536
+  if M > lim:
+    if lib.plm_embed_bwd_workspace_bytes(lim, dW.shape[0]) == 0:
+      return False
+    for lo in range(0, M, lim):
+      embed_bwd_sorted(ids[lo:lo + lim], dout[lo:lo + lim], dW, accumulate or lo > 0)
+    return True
   nbytes = lib.plm_embed_bwd_workspace_bytes(ids.numel(), dW.shape[0])
   if nbytes == 0:
     return False

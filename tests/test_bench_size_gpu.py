@@ -316,14 +316,15 @@ def test_160m_batch32_launch_vs_bf16_emulating_oracle(ops):
 # --------------------------------------------------------------------------------------
 # (d) the reference's configs AS SHIPPED: seq_len 2048 for the 160M model
 # --------------------------------------------------------------------------------------
-@pytest.mark.parametrize('B,masked', [(32, False), (8, True)])
+@pytest.mark.parametrize('B,masked', [(32, False), (8, True), (48, False)])
 def test_160m_seq2048_as_shipped_vs_oracle(ops, B, masked):
   """config/config.yaml:9,33 (seq_len 2048, micro_batch_size 32: M = 65536 token rows, logits [65536, 50304] = 3.3e9 elements - the first
   shape in the suite whose element and byte offsets pass 2^31 / 2^32; the sort-based embedding backward sits exactly on its M <= 65536 limit)
   and config_doc_mask.yaml:9,35 (seq_len 2048, micro_batch_size 8, document masks: the plan's split items at 32-tile costs).  The batch is ONE
   pair of sequences repeated B / 2 times, so the batch-mean loss and gradients ARE the pair's (fp32 oracle, one fwd+bwd of 2 x 2048 tokens
   on the CPU) while every kernel runs the shipped config's launch.  Loss within 1e-4, all 75 gradients (rel-to-max, relative L2 per class,
-  projection coefficient), two runs bit-equal."""
+  projection coefficient), two runs bit-equal.  B = 48 is beyond the shipped files: M = 98304 rows put the logits at 4.9e9 elements - past 2^32 - and
+  send the embedding backward through its sort in two slices."""
   import plainlm_amd as P
   T = 2048
   ocfg = O.OracleConfig(vocab_size=V160, seq_len=T, dim=768, n_layers=12, n_heads=12)

@@ -101,7 +101,8 @@ def test_embedding_fwd_bwd_repeated_ids(ops, golden_dir):
   close(dW, torch.from_numpy(z['emb_dw']), 1e-6, 'embedding bwd (golden)')
 
 
-@pytest.mark.parametrize('M,V,d', [(32768, 50280, 768), (4096, 256, 128), (1000, 65535, 64), (65536, 512, 256), (7, 3, 8)])
+@pytest.mark.parametrize('M,V,d', [(32768, 50280, 768), (4096, 256, 128), (1000, 65535, 64), (65536, 512, 256), (7, 3, 8),
+                                   (65537, 300, 64), (98304, 50280, 768), (200000, 1000, 32)])  # last three: more than one slice of 65536 tokens
 def test_embedding_bwd_sorted(ops, M, V, d):
   """Sort-based embedding backward: equals index_add (fp64 reference), ignores out-of-range ids, writes zeros into unused
   rows when overwriting, adds onto dW when accumulating, and is bit-reproducible (no atomics) - heavy duplicates included."""
