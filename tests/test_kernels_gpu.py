@@ -579,7 +579,8 @@ def _random_docs(B, T, seed):
   return out
 
 
-@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (1, 128, 1), (2, 256, 3), (1, 1024, 2), (1, 200, 2), (1, 2048, 1), (2, 320, 2), (3, 512, 1), (1, 836, 2)])
+@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (1, 128, 1), (2, 256, 3), (1, 1024, 2), (1, 200, 2), (1, 2048, 1), (2, 320, 2), (3, 512, 1), (1, 836, 2),
+                                    (100, 1024, 1), (1, 4096, 2)])  # 800 tiles: a plan in tile order (past the sort's limit); T = 4096
 @pytest.mark.parametrize('masked', [False, True])
 def test_attention_fwd_bwd(ops, B, T, nh, masked):
   g = torch.Generator().manual_seed(T * nh + masked)
@@ -636,13 +637,14 @@ def _plan_ref(ds, T, nh, split_min=8):
           items.append(((ca + 1) // 2 + 1, i, a, (b, r0 + 64 * a, ba, (1 << 30) | ca)))
       else:
         items.append((c, i, 0, (b, r0, wb, c)))
-    items.sort(key=lambda it: (-it[0], it[1], it[2]))
+    if n <= 768:  # DOC_PLAN_SORT_MAX: longer lists stay in tile order (and unsplit)
+      items.sort(key=lambda it: (-it[0], it[1], it[2]))
     recs = [it[3] for it in items]
     lists.append(recs)
   return de, lists[0], lists[1]
 
 
-@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (3, 200, 1), (8, 1024, 12), (2, 2048, 16), (5, 836, 3), (32, 1024, 12)])
+@pytest.mark.parametrize('B,T,nh', [(2, 64, 2), (3, 200, 1), (8, 1024, 12), (2, 2048, 16), (5, 836, 3), (32, 1024, 12), (48, 2048, 12), (50, 2048, 1)])  # last two: 768 (the sort's limit) and 800 tiles
 def test_attention_doc_plan(ops, B, T, nh):
   """plm_attn_doc_plan against its numpy restatement: header, doc_end[], both item lists (which tiles are split, bounds, order)."""
   ds = O.doc_start_from_lengths(_random_docs(B, T, 3 * T + B), T)
