@@ -211,6 +211,62 @@ def test_bench_two_ranks_on_one_device():
   assert 'did not finish' in out['extras_error'] and out['value'] > 0 and out['n_gpus'] == 2 and out['comm']['ranks'] == 2
 
 
+_BENCH_FAIL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+if os.environ['RANK'] == os.environ['FAIL_RANK']:
+  import plainlm_amd.optim as optim
+  def boom(*a, **k):
+    raise RuntimeError('injected failure')
+  optim.FlatAdamW = boom  # the full-step leg of this rank dies; the other rank is left inside that leg's collectives
+sys.argv = ['bench.py', '--gpus', '2', '--single-device', '--steps', '2', '--warmup', '1', '--no-autotune']
+bench.main()
+"""
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_survives_a_rank_that_dies_in_an_untimed_leg():
+  """One rank raises inside an untimed leg (after the timed region) while rank 0 is left waiting in that leg's collectives: rank 0 must still
+  print the ONE line of the timed region (with `extras_error`) and exit 0, and the failing rank must exit non-zero only AFTER that - a launcher
+  kills every rank as soon as one exits non-zero (bench.py::bail)."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  import json
+  import subprocess
+  import sys
+  import time
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  port = _free_port()
+  procs, t_end = [], {}
+  for r in range(2):
+    env = dict({k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}, RANK=str(r), LOCAL_RANK=str(r),
+               WORLD_SIZE='2', LOCAL_WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FAIL_RANK='1',
+               PLM_BENCH_EXTRAS_TIMEOUT='30', PLM_BENCH_EXIT_GRACE='3', OMP_NUM_THREADS='8')
+    procs.append(subprocess.Popen([sys.executable, '-c', _BENCH_FAIL_SCRIPT, root], cwd=root, env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True))
+  t0 = time.monotonic()
+  pending = {0, 1}
+  while pending and time.monotonic() - t0 < 500:
+    for r in list(pending):
+      if procs[r].poll() is not None:
+        t_end[r] = time.monotonic()
+        pending.discard(r)
+    time.sleep(0.1)
+  for p in procs:
+    if p.poll() is None:
+      p.kill()
+  outs = [p.communicate() for p in procs]
+  assert not pending, ('ranks still running', pending, outs[0][1][-1500:], outs[1][1][-1500:])
+  assert procs[0].returncode == 0 and procs[1].returncode == 3, (procs[0].returncode, procs[1].returncode, outs[0][1][-1500:], outs[1][1][-1500:])
+  lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+  assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')], (outs[0][0][-1000:], outs[1][0][-1000:])
+  out = json.loads(lines[0])
+  assert out['n_gpus'] == 2 and out['value'] > 0 and 'extras_error' in out and 'roofline' in out  # the leg before the failing one is in the line
+  assert t_end[1] >= t_end[0], 'the failing rank left before rank 0 had printed'
+  assert 'injected failure' in outs[1][1]
+
+
 _DDP_WRAPPER_SCRIPT = r'''
 import os, sys, json
 import numpy as np
