@@ -378,3 +378,28 @@ def test_register_budget_of_the_attention_and_128x128_gemm_kernels():
           assert meta['vgpr'] <= 168, (name, meta)
   assert seen >= 22, seen
 
+
+
+def test_every_entry_point_refuses_null_pointers_without_a_gpu():
+  """Error behaviour of the boundary (include/plainlm_hip.h): argument checks come before any HIP call, so they can be exercised here - every
+  int-returning entry point that takes a pointer answers a call with null pointers with a negative PLM_E_* code and a message that names the
+  entry point (plm_last_error_string), instead of launching or crashing.  (plm_comm_destroy(NULL) is a documented no-op.)"""
+  import ctypes as C
+  from plainlm_amd import _lib
+  lib = _lib.load()
+  checked = 0
+  for name, (restype, argtypes) in sorted(_lib.SIGNATURES.items()):
+    is_ptr = [a is _lib._P or (isinstance(a, type) and issubclass(a, C._Pointer)) for a in argtypes]
+    if restype is not _lib._I or not any(is_ptr):
+      continue
+    args = [None if p else (1.0 if a is _lib._F else 8) for a, p in zip(argtypes, is_ptr)]
+    rc = getattr(lib, name)(*args)
+    if name == 'plm_comm_destroy':
+      assert rc == 0
+      continue
+    msg = (lib.plm_last_error_string() or b'').decode()
+    assert rc < 0, (name, rc)
+    stem = name.replace('_ex', '').replace('_ws', '').replace('_capped', '')  # variants report under their family's name
+    assert stem in msg or name in msg, (name, msg)
+    checked += 1
+  assert checked >= 40, checked
