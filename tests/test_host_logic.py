@@ -403,3 +403,25 @@ def test_every_entry_point_refuses_null_pointers_without_a_gpu():
     assert stem in msg or name in msg, (name, msg)
     checked += 1
   assert checked >= 40, checked
+
+
+def test_shape_checks_of_the_boundary_without_a_gpu():
+  """The documented limits of a few entry points, asked with plausible (never dereferenced) pointers: the refusal comes from the argument
+  check, names the limit, and nothing is launched."""
+  import ctypes as C
+  from plainlm_amd import _lib
+  lib = _lib.load()
+  p = lambda: C.c_void_p(0x100000)
+  def refused(name, *args):
+    rc = getattr(lib, name)(*args)
+    assert rc < 0, (name, rc)
+    return (lib.plm_last_error_string() or b'').decode()
+  assert 'd % 4 == 0' in refused('plm_rmsnorm_fwd', p(), p(), p(), p(), p(), p(), 16, 6, 1e-6, None)
+  assert 'd <= 2048' in refused('plm_rmsnorm_fwd', p(), p(), p(), p(), p(), p(), 16, 4096, 1e-6, None)
+  assert 'head_dim 48 unsupported' in refused('plm_attn_fwd', p(), None, None, p(), p(), 2, 64, 2, 48, None)
+  assert 'multiple of 4' in refused('plm_attn_fwd', p(), None, None, p(), p(), 2, 63, 2, 64, None)
+  assert 'needs its plan' in refused('plm_attn_fwd', p(), p(), None, p(), p(), 2, 64, 2, 64, None)  # a document mask without a plan
+  assert 'aligned' in refused('plm_attn_fwd', C.c_void_p(0x100002), None, None, p(), p(), 2, 64, 2, 64, None)
+  assert 'M <= 65536' in refused('plm_embed_bwd_sorted', p(), p(), p(), 70000, 64, 1000, 0, p(), 1 << 20, None)
+  assert lib.plm_embed_bwd_workspace_bytes(70000, 1000) == 0 and lib.plm_embed_bwd_workspace_bytes(65536, 1000) > 0
+  assert lib.plm_attn_doc_plan_bytes(0, 64) == 0 and lib.plm_attn_doc_plan_bytes(8, 1024) > 4 * 8 * 1024
