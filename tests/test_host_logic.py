@@ -425,3 +425,17 @@ def test_shape_checks_of_the_boundary_without_a_gpu():
   assert 'M <= 65536' in refused('plm_embed_bwd_sorted', p(), p(), p(), 70000, 64, 1000, 0, p(), 1 << 20, None)
   assert lib.plm_embed_bwd_workspace_bytes(70000, 1000) == 0 and lib.plm_embed_bwd_workspace_bytes(65536, 1000) > 0
   assert lib.plm_attn_doc_plan_bytes(0, 64) == 0 and lib.plm_attn_doc_plan_bytes(8, 1024) > 4 * 8 * 1024
+
+
+def test_committed_pmc_traffic_profile_is_of_this_tree():
+  """`roofline.traffic` of the bench line comes from committed rocprofv3 PMC passes and is reported only when they were taken on THIS tree's
+  kernel sources (bench.csrc_sha).  A kernel change without a fresh `bash tools/profile_round.sh rNN` (and its pmc.json copied to
+  profiles/rNN_pmc_gemm_traffic.json) would silently turn the driver's `traffic` into null: fail here instead."""
+  import json
+  import bench
+  prof = bench._pmc_profile()
+  assert os.path.exists(prof), prof
+  assert json.load(open(prof)).get('csrc_sha') == bench.csrc_sha(), (
+      f'{os.path.basename(prof)} was taken on another tree: re-run tools/profile_round.sh on a GPU box and commit its pmc.json / pmc.txt')
+  got = bench.pmc_traffic('gemm_nt', '160m', 32768, 12)
+  assert got['traffic'] > got['algorithmic_bytes'] > 1e8 and got['csrc_sha'] == bench.csrc_sha()
