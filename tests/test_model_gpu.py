@@ -222,6 +222,39 @@ def _engine_cfg(**over):
   return namedtuple('Config', EC.keys())(**EC)
 
 
+def test_engine_soak_memory_stays_flat_and_loss_falls(P, mdl):
+  """A long run must not grow: 60 optimizer steps (accumulation 2, document masks with NEW random documents - a new plan - at every micro-step,
+  host batches) of the small model; device memory allocated is the same after step 10 and after step 60, reserved memory does not grow, and
+  the loss on the fixed 4-batch pool falls (tools/engine_soak.py is the same run on the 160M config: profiles/r06_engine_soak.txt)."""
+  cfg = _engine_cfg(grad_accumulation_steps=2, steps_budget=60, warmup_steps=5, intra_doc_masking=True, micro_batch_size=4)
+  model, _ = P.construct_model(cfg)
+  model.load_state_dict(_weights(mdl))
+  eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  rng = np.random.default_rng(5)
+  pool = rng.integers(0, 256, size=(4, 4, 65))
+
+  def batch(i):
+    rows = []
+    for _ in range(4):
+      lens, tot = [], 0
+      while tot < 65:
+        n = int(min(rng.geometric(1.0 / 16.0), 65 - tot))
+        lens.append(n)
+        tot += n
+      rows.append(lens)
+    return {'input_ids': torch.from_numpy(pool[i % 4]), 'docs_lengths': rows}
+
+  marks, losses = {}, []
+  for i in range(120):
+    losses.append(float(eng.step(batch(i))))
+    if i + 1 in (20, 120):
+      torch.cuda.synchronize()
+      marks[i + 1] = (torch.cuda.memory_allocated(), torch.cuda.memory_reserved())
+  assert marks[120][0] == marks[20][0], marks
+  assert marks[120][1] <= marks[20][1], marks
+  assert np.mean(losses[-8:]) < 0.6 * np.mean(losses[:8]), (losses[:8], losses[-8:])
+
+
 def test_engine_loss_sequence_vs_reference(P, mdl, golden_dir):
   """engine/engine.py:93-141: 16 micro-steps = 4 optimizer steps (accum 4, clip 1.0, AdamW, warmup-cosine; lr 0, 1.5e-3,
   3e-3, 2.8e-3) against (a) the losses the reference's own TorchEngine produced on CPU fp32 and (b) the bf16-emulating
