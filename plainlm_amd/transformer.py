@@ -220,6 +220,9 @@ class Transformer(nn.Module):
     self.head_dim = cfg.dim // cfg.n_heads
     if self.head_dim not in (32, 64, 128):  # 64: the tuned kernels (every shipped config); 32 / 128: csrc/attn_generic.hip
       raise NotImplementedError(f'head_dim {self.head_dim}: the gfx950 attention kernels are built for head dims 32, 64 and 128')
+    if cfg.vocab_size % 8 != 0:  # 16-byte rows of the bf16 lm_head shadows and of the logits (every shipped config: 50280)
+      raise NotImplementedError(f'vocab_size {cfg.vocab_size}: must be a multiple of 8 on this path - pad the vocabulary (GPT-2\'s 50257 -> 50264; the '
+                                f'reference\'s configs ship 50280), the extra rows are ordinary never-targeted tokens')
 
     self.embed_tokens = HipEmbedding(cfg.vocab_size, cfg.dim)
     self.layers = nn.ModuleList([Block(idx, cfg) for idx in range(cfg.n_layers)])

@@ -92,6 +92,8 @@ def test_unsupported_configs_fail_loudly():
   assert P.construct_model(_cfg(n_heads=4))[0].head_dim == 32 and P.construct_model(_cfg(n_heads=1))[0].head_dim == 128
   with pytest.raises(ValueError):
     P.construct_model(_cfg(d_model=100, n_heads=3))
+  with pytest.raises(NotImplementedError, match='multiple of 8'):
+    P.construct_model(_cfg(vocab_size=50257))  # GPT-2's vocabulary unpadded: refused at construction, with the remedy in the message
 
 
 def test_no_cpu_fallback():

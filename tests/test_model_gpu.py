@@ -348,6 +348,62 @@ def test_model_other_head_dims_vs_oracle(P, nh, masked):
   assert len(worst) == 15 and max(worst.values()) < 4e-2, worst
 
 
+def _random_model_case(seed):
+  rng = np.random.default_rng(1000 + seed)
+  hd = int(rng.choice([32, 64, 64, 128]))
+  nh = int(rng.integers(1, 4))
+  T = int(rng.choice([36, 64, 100, 128, 200, 260]))
+  return dict(hd=hd, nh=nh, dim=hd * nh, T=T, B=int(rng.integers(1, 5)), V=int(rng.choice([96, 256, 1000, 3000])), L=int(rng.integers(1, 4)),
+              mlp=str(rng.choice(['glu', 'glu', 'mlp', 'mlp_relu_sq'])), tied=bool(rng.integers(0, 2)), masked=bool(rng.integers(0, 2)),
+              expand=float(rng.choice([8 / 3, 2.0, 4.0])), main_grad=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize('seed', range(32))
+def test_random_model_configs_vs_oracle(P, seed):
+  """The options of the module API in random COMBINATIONS (each has its own test; their interactions have this one): head_dim 32 / 64 / 128 x
+  heads x layers x ragged sequence lengths and vocabularies x the three MLP classes x `expand` x tied embeddings x document masks x the two
+  gradient paths (autograd .grad / the engine's flat buffer).  Loss within 1e-4 of the fp32 oracle, every gradient within the bf16 floor."""
+  c = _random_model_case(seed)
+  ocfg = O.OracleConfig(vocab_size=c['V'], seq_len=c['T'], dim=c['dim'], n_layers=c['L'], n_heads=c['nh'], expand=c['expand'], tie_embeddings=c['tied'],
+                        mlp=c['mlp'])
+  w = O.init_params(ocfg, seed=seed)
+  rng = np.random.default_rng(seed)
+  tok = torch.from_numpy(rng.integers(0, c['V'], size=(c['B'], c['T'] + 1)))
+  ids, tgt = tok[:, :c['T']].contiguous(), tok[:, 1:].contiguous()
+  ds = None
+  if c['masked']:
+    rows = []
+    for _ in range(c['B']):
+      lens, tot = [], 0
+      while tot < c['T'] + 1:
+        n = int(min(rng.geometric(1.0 / 24.0), c['T'] + 1 - tot))
+        lens.append(n)
+        tot += n
+      rows.append(lens)
+    ds = O.doc_start_from_lengths(rows, c['T'])
+  m = P.Transformer(P.ModelConfig(vocab_size=c['V'], seq_len=c['T'], dim=c['dim'], expand=c['expand'], n_layers=c['L'], n_heads=c['nh'], mlp=c['mlp'],
+                                  tie_embeddings=c['tied']))
+  m.load_state_dict({**w, **({'lm_head.weight': w['embed_tokens.weight']} if c['tied'] and 'lm_head.weight' not in w else {})})
+  m = m.cuda()
+  if c['main_grad']:
+    m.enable_main_grad()
+    m.sink.begin_window()
+  loss = m.loss(ids.cuda(), tgt.cuda(), None if ds is None else ds.cuda())
+  loss.backward()
+  if c['main_grad']:
+    m.attach_grads()
+  oloss, og = O.loss_and_grads(w, ocfg, ids, tgt, ds)
+  rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
+  assert rel <= LOSS_RTOL, (c, loss.item(), oloss.item())
+  seen = 0
+  for n, p in m.named_parameters():
+    if n in og:
+      seen += 1
+      e = relmax(p.grad.float().cpu(), og[n])
+      assert e < 5e-2, (c, n, e)
+  assert seen == len(og), (seen, len(og))
+
+
 def test_engine_cfg1_literal_shape_vs_reference(P, golden_dir):
   """BASELINE configs[0] at its literal shape through HipEngine on the GPU: 2 layers, d = 128, 2 heads, seq 128, the REAL vocabulary
   (50 280: with d = 128 the ragged lm_head and its gradient GEMMs take the small-shape kernels no other model-level test reaches),
