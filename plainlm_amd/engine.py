@@ -24,7 +24,8 @@ from .construct import get_param_groups
 from . import ddp
 
 
-# ---- LR schedules (optim/lr_schedule.py:29-105), host-side scalar math --------------------
+# ---- LR schedules (optim/lr_schedule.py:29-132), host-side scalar math --------------------
+# (state_dict() keeps the reference's attribute names: scheduler states travel in checkpoints, checkpoint_utils.py:22-24)
 class _Schedule:
   def __init__(self, optimizer):
     self.optimizer = optimizer
@@ -72,12 +73,52 @@ class WarmupConstant(_Schedule):
     return self.lr_max
 
 
+def _ramp(t, t0, n, y0, y1):
+  """the straight line through (t0, y0) and (t0 + n, y1), at t"""
+  return y0 + (y1 - y0) / n * (t - t0)
+
+
+class WSD(_Schedule):
+  """Trapezoid (optim/lr_schedule.py:57-82): linear warm-up, a plateau at lr_max up to `cooldown_start_step`, then a straight line that
+  reaches lr_end `cooldown_steps` later (and keeps its slope beyond, like the reference's)."""
+
+  def __init__(self, optimizer, lr_start, lr_max, lr_end, warmup_steps, cooldown_start_step, cooldown_steps):
+    super().__init__(optimizer)
+    self.lr_start, self.lr_max, self.lr_end = lr_start, lr_max, lr_end
+    self.warmup_steps, self.cooldown_start_step, self.cooldown_steps, self.iter = warmup_steps, cooldown_start_step, cooldown_steps, 0
+    self.set_optim_lr(lr_start)
+
+  def get_lr(self, t):
+    if t <= self.warmup_steps:
+      return _ramp(t, 0, self.warmup_steps, self.lr_start, self.lr_max)
+    if t <= self.cooldown_start_step:
+      return self.lr_max
+    return _ramp(t, self.cooldown_start_step, self.cooldown_steps, self.lr_max, self.lr_end)
+
+
+class LinearCooldown(_Schedule):
+  """The cool-down leg alone, for a run resumed at `cooldown_start_step` (optim/lr_schedule.py:108-132).  Like the reference's it leaves the
+  optimizer's learning rate alone until its first step, and takes ONLY `iter` from a saved state (the other fields come from the new config)."""
+
+  def __init__(self, optimizer, lr_max, lr_end, cooldown_start_step, cooldown_steps):
+    super().__init__(optimizer)
+    self.lr_max, self.lr_end, self.cooldown_start_step, self.cooldown_steps, self.iter = lr_max, lr_end, cooldown_start_step, cooldown_steps, 0
+
+  def get_lr(self, t):
+    if t <= self.cooldown_start_step:
+      return self.lr_max
+    return _ramp(t, self.cooldown_start_step, self.cooldown_steps, self.lr_max, self.lr_end)
+
+  def load_state_dict(self, state):
+    self.iter = state.get('iter', 0)
+
+
 def _steps(value, budget):
   return value if isinstance(value, int) else int(value * budget)
 
 
 def initialize_scheduler(optimizer, cfg):
-  """optim/init_optim.py:73-137 for the schedulers on the shipped configs' path."""
+  """optim/init_optim.py:73-137: the reference's four schedulers."""
   name = getattr(cfg, 'scheduler', None)
   if name is None:
     return None
@@ -89,6 +130,11 @@ def initialize_scheduler(optimizer, cfg):
     return WarmupCosine(optimizer, cfg.lr_start, cfg.lr, lr_end, warmup, cfg.steps_budget)
   if name == 'warmup_constant':
     return WarmupConstant(optimizer, cfg.lr_start, cfg.lr, warmup)
+  cooldown = _steps(cfg.cooldown_steps, cfg.steps_budget) if getattr(cfg, 'cooldown_steps', None) is not None else None
+  if name == 'wsd':
+    return WSD(optimizer, cfg.lr_start, cfg.lr, lr_end, warmup, cfg.steps_budget - cooldown, cooldown)
+  if name == 'linear_cooldown':
+    return LinearCooldown(optimizer, cfg.lr, lr_end, cfg.resume_step, cooldown)
   raise NotImplementedError(f'Not implemented scheduler: {name}.')
 
 
@@ -225,7 +271,8 @@ class HipEngine(torch.nn.Module):
 
     if getattr(cfg, 'resume', False):
       self.optimizer.load_state_dict(ckpt['optimizer'])
-      self.scheduler.load_state_dict(ckpt['scheduler'])
+      if self.scheduler is not None:
+        self.scheduler.load_state_dict(ckpt['scheduler'])
       self.scaler.load_state_dict(ckpt['scaler'])
 
   def step(self, batch):

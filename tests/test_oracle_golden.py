@@ -281,3 +281,34 @@ def test_reference_resumes_hip_checkpoint(golden_dir):
                      capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
   assert 'reference engine resumed from the HipEngine checkpoint' in r.stdout
+
+
+def test_lr_schedules_vs_reference(golden_dir):
+  """The reference's four schedulers through its initialize_scheduler (optim/init_optim.py:73-137; fixture: tests/golden/make_schedules.py, the
+  reference imported in the build container): the learning rate before the first step and after every step - integer and fractional warm-up /
+  cool-down lengths, lr_end and lr_end_pct, steps past the budget - bit for bit, and the state_dict (it travels in checkpoints,
+  checkpoint_utils.py:22-24) key for key.  LinearCooldown takes only `iter` from a saved state, like the reference's."""
+  import json
+  from types import SimpleNamespace
+  from plainlm_amd import engine
+  cases = json.load(open(os.path.join(golden_dir, 'schedules.json')))
+  assert {c['cfg']['scheduler'] for c in cases} == {'warmup_cosine', 'warmup_constant', 'wsd', 'linear_cooldown'}
+  for c in cases:
+    cfg = SimpleNamespace(**{k: v for k, v in c['cfg'].items() if k != 'n'})
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=cfg.lr)
+    sch = engine.initialize_scheduler(opt, cfg)
+    lrs = [opt.param_groups[0]['lr']]
+    for _ in range(c['cfg']['n']):
+      sch.step()
+      lrs.append(opt.param_groups[0]['lr'])
+    assert lrs == c['lrs'], (c['cfg'], lrs, c['lrs'])
+    assert sch.state_dict() == c['state'], (c['cfg'], sch.state_dict(), c['state'])
+    # a fresh scheduler resumed from the saved state continues the sequence
+    opt2 = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=cfg.lr)
+    s2 = engine.initialize_scheduler(opt2, cfg)
+    s2.load_state_dict(dict(c['state'], iter=3))
+    s2.step()
+    assert opt2.param_groups[0]['lr'] == c['lrs'][4], c['cfg']
+  with pytest.raises(NotImplementedError):
+    engine.initialize_scheduler(opt, SimpleNamespace(scheduler='one_cycle', warmup_steps=1, steps_budget=4, lr_end=None, lr_end_pct=None, lr=1.0, lr_start=0.0))
+  assert engine.initialize_scheduler(opt, SimpleNamespace(scheduler=None)) is None
