@@ -255,17 +255,19 @@ def test_engine_soak_memory_stays_flat_and_loss_falls(P, mdl):
   assert np.mean(losses[-8:]) < 0.6 * np.mean(losses[:8]), (losses[:8], losses[-8:])
 
 
-def test_engine_loss_sequence_vs_reference(P, mdl, golden_dir):
+@pytest.mark.parametrize('fused', [True, False])  # fused_optim: FlatAdamW on the flat buffers (the shipped configs) / torch.optim.AdamW + clip_grad_norm_ on the views
+def test_engine_loss_sequence_vs_reference(P, mdl, golden_dir, fused):
   """engine/engine.py:93-141: 16 micro-steps = 4 optimizer steps (accum 4, clip 1.0, AdamW, warmup-cosine; lr 0, 1.5e-3,
   3e-3, 2.8e-3) against (a) the losses the reference's own TorchEngine produced on CPU fp32 and (b) the bf16-emulating
   oracle engine run in lock step.  North-star tolerance 1e-4 on ALL 16 micro-steps, i.e. also on the 8 that follow real
   parameter updates.  (tests/test_oracle_golden.py shows that bf16 rounding alone moves this trajectory by < 5e-5.)"""
   from oracle import cpu_ref_bf16 as E
   en = np.load(os.path.join(golden_dir, 'engine.npz'))
-  cfg = _engine_cfg()
+  cfg = _engine_cfg(fused_optim=fused)
   model, _ = P.construct_model(cfg)
   model.load_state_dict(_weights(mdl))
   eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+  assert hasattr(eng.optimizer, 'clip_and_step') == fused and (fused or isinstance(eng.optimizer, torch.optim.AdamW))
   ocfg = O.OracleConfig(vocab_size=256, seq_len=64, dim=128, n_layers=2, n_heads=2)
   emu = E.OracleEngineBF16(_weights(mdl), ocfg, lr=3e-3, weight_decay=0.1, beta1=0.9, beta2=0.95, grad_clip=1.0, accum=4,
                            steps_budget=8, warmup_steps=2)
