@@ -222,6 +222,48 @@ def _engine_cfg(**over):
   return namedtuple('Config', EC.keys())(**EC)
 
 
+@pytest.mark.parametrize('opts', [
+  dict(grad_clip=None, scheduler=None, weight_decay=0.0, lr=1e-3),
+  dict(grad_clip=0.3, scheduler='wsd', warmup_steps=1, cooldown_steps=2, steps_budget=6, grad_accumulation_steps=2),
+  dict(grad_clip=None, scheduler='warmup_constant', warmup_steps=2, grad_accumulation_steps=3, tie_embeddings=True),
+  dict(grad_clip=1.0, scheduler='linear_cooldown', resume_step=1, cooldown_steps=3, lr_end=None, lr_end_pct=0.1, grad_accumulation_steps=1),
+])
+def test_engine_options_fused_optimizer_equals_torch_adamw(P, mdl, opts):
+  """Engine options off the shipped configs' values - no gradient clipping (`grad_clip: null`), no scheduler, zero weight decay, the wsd /
+  warmup_constant / linear_cooldown schedulers, other accumulation lengths, tied embeddings: the fused optimizer tail (FlatAdamW kernels on
+  the flat buffers) against the reference's own tail, torch.optim.AdamW + clip_grad_norm_ on the views (fused_optim False), same weights, same
+  batches.  Identical losses while the weights are identical (first window), within 2e-4 afterwards; learning rates equal; final weights
+  equal up to sign flips of near-zero updates."""
+  en = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'engine.npz'))
+  tokens = torch.from_numpy(en['tokens'])
+  runs = {}
+  for fused in (True, False):
+    cfg = _engine_cfg(fused_optim=fused, **opts)
+    model, _ = P.construct_model(cfg)
+    w = _weights(mdl)
+    if cfg.tie_embeddings:
+      w['lm_head.weight'] = w['embed_tokens.weight']
+    model.load_state_dict(w)
+    eng = P.TorchEngine(model, cfg, 'cuda', None, None)
+    losses, lrs = [], []
+    for i in range(12):
+      losses.append(float(eng.step({'input_ids': tokens[i % tokens.shape[0]]})))
+      lrs.append(eng.optimizer.param_groups[0]['lr'])
+    runs[fused] = (losses, lrs, {n: p.detach().float().cpu() for n, p in eng.model.named_parameters()})
+  (lf, rf, pf), (lt, rt, pt) = runs[True], runs[False]
+  acc = opts.get('grad_accumulation_steps', 4)
+  assert lf[:acc] == lt[:acc], (lf[:acc], lt[:acc])
+  # afterwards both are bf16 trajectories of their own (the accumulation of a window's gradients rounds differently in the flat buffer and in
+  # .grad, and AdamW turns the sign of a near-zero gradient into a full step): each stays within 1e-4 of the fp32 trajectory, so within 2e-4 of
+  # the other
+  np.testing.assert_allclose(lf, lt, rtol=2e-4)
+  assert rf == rt, (rf, rt)
+  lr = max(rt) or opts.get('lr', 3e-3)
+  for n in pf:  # AdamW moves a weight by ~lr per step whatever its gradient: a sign flip moves ONE element by 2 lr; > 2 % of a tensor is a bug
+    frac_off = ((pf[n] - pt[n]).abs() > 0.5 * lr).float().mean().item()
+    assert frac_off < 0.02, (n, frac_off)
+
+
 def test_engine_soak_memory_stays_flat_and_loss_falls(P, mdl):
   """A long run must not grow: 60 optimizer steps (accumulation 2, document masks with NEW random documents - a new plan - at every micro-step,
   host batches) of the small model; device memory allocated is the same after step 10 and after step 60, reserved memory does not grow, and
