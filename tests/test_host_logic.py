@@ -441,3 +441,42 @@ def test_committed_pmc_traffic_profile_is_of_this_tree():
       f'{os.path.basename(prof)} was taken on another tree: re-run tools/profile_round.sh on a GPU box and commit its pmc.json / pmc.txt')
   got = bench.pmc_traffic('gemm_nt', '160m', 32768, 12)
   assert got['traffic'] > got['algorithmic_bytes'] > 1e8 and got['csrc_sha'] == bench.csrc_sha()
+
+
+def test_bucket_plan_properties_on_random_layouts():
+  """plan_buckets on 300 random flat layouts (parameter sizes over five orders of magnitude, permuted span tables, random block groups of
+  adjacent parameters, random caps): the buckets tile the flat buffer exactly once, each is one contiguous span, walks from the END of the buffer
+  (bucket k lies above bucket k + 1), holds at most `cap` bytes unless it is a single parameter - or unless the small trailing bucket was merged into
+  it - and a block group that fits a bucket is never split."""
+  rng = np.random.default_rng(2024)
+  for case in range(300):
+    n = int(rng.integers(1, 40))
+    sizes = [int(10 ** rng.uniform(0, 5.5)) for _ in range(n)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    spans = [(int(offs[i]), sizes[i]) for i in range(n)]
+    perm = list(rng.permutation(n))
+    table = [spans[i] for i in perm]           # the span table in another order than the buffer
+    pos = {int(p): k for k, p in enumerate(perm)}  # buffer index -> table index
+    groups, i = [], 0
+    while i < n:
+      g = int(rng.integers(1, 6))
+      if rng.random() < 0.5 and i + g <= n:
+        groups.append([pos[j] for j in range(i, i + g)])
+      i += g
+    cap = int(4 * 10 ** rng.uniform(1, 6))
+    out = ddp.plan_buckets(table, cap, groups=groups or None)
+    total = int(offs[-1])
+    cover = sorted((lo, hi) for lo, hi, _ in out)
+    assert cover[0][0] == 0 and cover[-1][1] == total and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), (case, cover)
+    assert [lo for lo, _, _ in out] == sorted((lo for lo, _, _ in out), reverse=True), case  # from the end of the buffer backwards
+    seen = sorted(i for _, _, idxs in out for i in idxs)
+    assert seen == list(range(n)), case
+    bucket_of = {i: k for k, (_, _, idxs) in enumerate(out) for i in idxs}
+    for k, (lo, hi, idxs) in enumerate(out):
+      assert hi - lo == sum(table[i][1] for i in idxs), case
+      merged_tail = k == len(out) - 1 and len(out) >= 1  # the last bucket may have absorbed a < 1 MiB trailing one
+      assert (hi - lo) * 4 <= cap or len(idxs) == 1 or merged_tail, (case, k, (hi - lo) * 4, cap)
+    for g in groups:
+      if sum(table[i][1] for i in g) * 4 <= cap and len({bucket_of[i] for i in g}) > 1:
+        # allowed only through the tail merge (the group then still sits in ONE bucket) - anything else is a split group
+        raise AssertionError((case, 'group split', g, [bucket_of[i] for i in g]))
